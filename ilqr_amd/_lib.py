@@ -1,0 +1,80 @@
+"""ctypes binding of libilqr_hip.so (C ABI declared in include/ilqr_hip.h).
+
+The shared library is the only compute path: if it is missing or cannot be
+loaded this module raises, there is no CPU fallback.  PyTorch is used only to
+own device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libilqr_hip.so")
+
+MODEL_CAR, MODEL_ACROBOT, MODEL_QUAD_EA, MODEL_QUAD_QUAT = 0, 1, 2, 3
+EXIT_DTOL, EXIT_SMALL_DELTAJ, EXIT_MAXITER, EXIT_LINALG = 0, 1, 2, 3
+EXIT_NAMES = {0: "d_tol", 1: "deltaJ<1", 2: "max_iter", 3: "linalg_error"}
+FLAG_PARALLEL_LS = 1
+
+EXPORTS = ("ilqr_model_info", "ilqr_workspace_bytes", "ilqr_solve_batch", "ilqr_rollout_cost",
+           "ilqr_model_eval", "ilqr_mpc_advance", "ilqr_last_error", "ilqr_version")
+
+_dp = C.c_void_p  # device pointers travel as plain addresses
+
+
+class Problem(C.Structure):
+    _fields_ = [("model_id", C.c_int32), ("N", C.c_int32), ("max_iter", C.c_int32), ("max_ls", C.c_int32),
+                ("d_tol", C.c_double), ("B", C.c_int64), ("stride", C.c_int64), ("params", _dp),
+                ("trace_len", C.c_int32), ("flags", C.c_int32)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [(k, _dp) for k in ("J0", "J", "dmax", "max_abs_q", "iters", "status", "regu_rounds", "ls_total",
+                                   "ls_evals", "accepted", "J_trace", "deltaJ_trace")]
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libilqr_hip.so (once).  Raises LibraryMissing when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.ilqr_model_info.restype = C.c_int
+    L.ilqr_model_info.argtypes = [C.c_int32] + [C.POINTER(C.c_int32)] * 4
+    L.ilqr_workspace_bytes.restype = C.c_size_t
+    L.ilqr_workspace_bytes.argtypes = [C.POINTER(Problem)]
+    L.ilqr_solve_batch.restype = C.c_int
+    L.ilqr_solve_batch.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, C.POINTER(Outputs), _dp, C.c_size_t, _dp]
+    L.ilqr_rollout_cost.restype = C.c_int
+    L.ilqr_rollout_cost.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, _dp, _dp]
+    L.ilqr_model_eval.restype = C.c_int
+    L.ilqr_model_eval.argtypes = [C.POINTER(Problem)] + [_dp] * 15
+    L.ilqr_mpc_advance.restype = C.c_int
+    L.ilqr_mpc_advance.argtypes = [C.POINTER(Problem), _dp, _dp, _dp]
+    L.ilqr_last_error.restype = C.c_char_p
+    L.ilqr_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError(f"libilqr_hip error {rc}: {lib().ilqr_last_error().decode()}")
+
+
+def model_info(model_id: int):
+    v = [C.c_int32() for _ in range(4)]
+    check(lib().ilqr_model_info(model_id, *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)

@@ -1,0 +1,333 @@
+// Plant models as compile-time policies for the gfx950 kernels.
+//
+// Each policy gives the dimensions and the five operations the reference's
+// Model interface defines (control/models/model.py:9-53): discrete_dynamics,
+// _cost_stage, _cost_final, stage, final, plus CalcDifferentialState.  The
+// straight-line arithmetic comes from the generated headers in gen/ (SymPy
+// differentiation done offline, in place of the reference's run-time
+// pydrake.symbolic / CasADi evaluation).
+//
+// All matrices are row-major in per-lane private arrays.  stage()/final()
+// return cost derivatives in the ndx-dimensional error state, so the generic
+// Q-function assembly of model.py:45-53 applies to every plant; for the
+// quaternion plant that means the projections l_x G, G' l_xx G, l_ux G of
+// Quadrotor_Quat.py:267-275 are applied inside stage().
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gen/acrobot_gen.h"
+#include "gen/car_gen.h"
+#include "gen/quad_ea_gen.h"
+#include "gen/quad_quat_gen.h"
+
+namespace ilqr {
+
+// Loop-unrolling policy: small plants keep every matrix in registers (fully
+// unrolled loops, compile-time indices); the 12-state plants keep loops rolled
+// so their matrices live in per-lane private memory.
+#define ILQR_UNROLL_IF(cond) _Pragma("unroll")
+
+template <int NX>
+__device__ __forceinline__ void diff_sub(const double* s, const double* r, double* dx)
+{
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[i] = s[i] - r[i];   // model.py:22-23
+}
+
+// ---------------------------------------------------------------- car
+struct CarModel {
+    static constexpr int NX = 5, NU = 2, NDX = 5, NPAR = 2;
+    static constexpr bool UNROLL = true;
+    __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
+    {
+        car_gen_dynamics(par, x, u, xn);
+    }
+    __device__ static double cost_stage(const double* par, const double* x, const double* u)
+    {
+        double c;
+        car_gen_cost_stage(par, x, u, &c);
+        return c;
+    }
+    __device__ static double cost_final(const double* par, const double* x)
+    {
+        double c;
+        car_gen_cost_final(par, x, &c);
+        return c;
+    }
+    __device__ static void stage(const double* par, const double* x, const double* u, double* lx, double* lu,
+                                 double* lxx, double* lux, double* luu, double* fx, double* fu)
+    {
+        car_gen_stage(par, x, u, lx, lu, lxx, lux, luu, fx, fu);
+    }
+    __device__ static void final(const double* par, const double* x, double* Vx, double* Vxx)
+    {
+        car_gen_final(par, x, Vx, Vxx);
+    }
+    __device__ static void diff_state(const double*, const double* s, const double* r, double* dx)
+    {
+        diff_sub<NX>(s, r, dx);
+    }
+};
+
+// ------------------------------------------------- RK4 (acrobot.py:76-97)
+template <int NX, void (*XDOT)(const double*, const double*, double*)>
+__device__ inline void rk4_step(double dt, const double* x, const double* u, double* xn)
+{
+    double f1[NX], f2[NX], f3[NX], f4[NX], xs[NX];
+    XDOT(x, u, f1);
+    for (int i = 0; i < NX; ++i) xs[i] = x[i] + 0.5 * f1[i] * dt;
+    XDOT(xs, u, f2);
+    for (int i = 0; i < NX; ++i) xs[i] = x[i] + 0.5 * f2[i] * dt;
+    XDOT(xs, u, f3);
+    for (int i = 0; i < NX; ++i) xs[i] = x[i] + 1.0 * f3[i] * dt;
+    XDOT(xs, u, f4);
+    for (int i = 0; i < NX; ++i) xn[i] = x[i] + (f1[i] + 2 * f2[i] + 2 * f3[i] + f4[i]) * dt / 6.0;
+}
+
+// Kx = A (I + c Kxp), Ku = A (c Kup) + B; accumulates w*Kx, w*Ku into Sx, Su.
+template <int NX, int NU>
+__device__ inline void rk4_chain(double c, double w, const double* A, const double* B, double* Kx, double* Ku,
+                                 double* Sx, double* Su)
+{
+    // Kx/Ku hold the previous stage on entry and the new stage on exit.
+    double Tx[NX * NX], Tu[NX * NU];
+    for (int i = 0; i < NX; ++i) {
+        for (int j = 0; j < NX; ++j) Tx[i * NX + j] = (i == j ? 1.0 : 0.0) + c * Kx[i * NX + j];
+        for (int j = 0; j < NU; ++j) Tu[i * NU + j] = c * Ku[i * NU + j];
+    }
+    for (int i = 0; i < NX; ++i) {
+        for (int j = 0; j < NX; ++j) {
+            double s = 0.0;
+            for (int t = 0; t < NX; ++t) s += A[i * NX + t] * Tx[t * NX + j];
+            Kx[i * NX + j] = s;
+            Sx[i * NX + j] += w * s;
+        }
+        for (int j = 0; j < NU; ++j) {
+            double s = 0.0;
+            for (int t = 0; t < NX; ++t) s += A[i * NX + t] * Tu[t * NU + j];
+            s += B[i * NU + j];
+            Ku[i * NU + j] = s;
+            Su[i * NU + j] += w * s;
+        }
+    }
+}
+
+// d x_next/dx and d x_next/du of one RK4 step: the chain rule through the four
+// stages, i.e. what CasADi's ca.jacobian of the RK4 graph evaluates
+// (acrobot.py:92-93, Quadrotor_EA.py:148-149, Quadrotor_Quat.py:132-133).
+template <int NX, int NU, void (*XDOTJAC)(const double*, const double*, double*, double*, double*)>
+__device__ inline void rk4_jac(double dt, const double* x, const double* u, double* Fx, double* Fu)
+{
+    double f[NX], xs[NX], A[NX * NX], B[NX * NU], Kx[NX * NX], Ku[NX * NU];
+    XDOTJAC(x, u, f, Kx, Ku);
+    for (int i = 0; i < NX * NX; ++i) Fx[i] = Kx[i];
+    for (int i = 0; i < NX * NU; ++i) Fu[i] = Ku[i];
+    for (int i = 0; i < NX; ++i) xs[i] = x[i] + 0.5 * f[i] * dt;
+    XDOTJAC(xs, u, f, A, B);
+    rk4_chain<NX, NU>(0.5 * dt, 2.0, A, B, Kx, Ku, Fx, Fu);
+    for (int i = 0; i < NX; ++i) xs[i] = x[i] + 0.5 * f[i] * dt;
+    XDOTJAC(xs, u, f, A, B);
+    rk4_chain<NX, NU>(0.5 * dt, 2.0, A, B, Kx, Ku, Fx, Fu);
+    for (int i = 0; i < NX; ++i) xs[i] = x[i] + 1.0 * f[i] * dt;
+    XDOTJAC(xs, u, f, A, B);
+    rk4_chain<NX, NU>(dt, 1.0, A, B, Kx, Ku, Fx, Fu);
+    for (int i = 0; i < NX; ++i) {
+        for (int j = 0; j < NX; ++j) Fx[i * NX + j] = (i == j ? 1.0 : 0.0) + Fx[i * NX + j] * dt / 6.0;
+        for (int j = 0; j < NU; ++j) Fu[i * NU + j] = Fu[i * NU + j] * dt / 6.0;
+    }
+}
+
+// --------------------- quadratic-cost RK4 plants (acrobot.py, Quadrotor_EA.py)
+// parameter block: [dt, Q(nx*nx), Qf(nx*nx), R(nu*nu), xref(nx), uref(nu)]
+template <int NX_, int NU_, bool UNROLL_, void (*XDOT)(const double*, const double*, double*),
+          void (*XDOTJAC)(const double*, const double*, double*, double*, double*)>
+struct QuadraticRK4Model {
+    static constexpr int NX = NX_, NU = NU_, NDX = NX_;
+    static constexpr int NPAR = 1 + 2 * NX * NX + NU * NU + NX + NU;
+    static constexpr bool UNROLL = UNROLL_;
+    __device__ static const double* Qm(const double* p) { return p + 1; }
+    __device__ static const double* Qf(const double* p) { return p + 1 + NX * NX; }
+    __device__ static const double* Rm(const double* p) { return p + 1 + 2 * NX * NX; }
+    __device__ static const double* xref(const double* p) { return p + 1 + 2 * NX * NX + NU * NU; }
+    __device__ static const double* uref(const double* p) { return p + 1 + 2 * NX * NX + NU * NU + NX; }
+
+    __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
+    {
+        rk4_step<NX, XDOT>(par[0], x, u, xn);
+    }
+    // 0.5 e'We evaluated as ((0.5 e)' W) e  (acrobot.py:119-120, :127)
+    template <int D>
+    __device__ static double half_form(const double* W, const double* e)
+    {
+        double s = 0.0;
+        for (int j = 0; j < D; ++j) {
+            double t = 0.0;
+            for (int i = 0; i < D; ++i) t += (0.5 * e[i]) * W[i * D + j];
+            s += t * e[j];
+        }
+        return s;
+    }
+    __device__ static double cost_stage(const double* par, const double* x, const double* u)
+    {
+        double ex[NX], eu[NU];
+        for (int i = 0; i < NX; ++i) ex[i] = x[i] - xref(par)[i];
+        for (int i = 0; i < NU; ++i) eu[i] = u[i] - uref(par)[i];
+        return half_form<NX>(Qm(par), ex) + half_form<NU>(Rm(par), eu);
+    }
+    __device__ static double cost_final(const double* par, const double* x)
+    {
+        double ex[NX];
+        for (int i = 0; i < NX; ++i) ex[i] = x[i] - xref(par)[i];
+        return half_form<NX>(Qf(par), ex);
+    }
+    // acrobot.py:152-161 / Quadrotor_EA.py:210-219
+    __device__ static void stage(const double* par, const double* x, const double* u, double* lx, double* lu,
+                                 double* lxx, double* lux, double* luu, double* fx, double* fu)
+    {
+        rk4_jac<NX, NU, XDOTJAC>(par[0], x, u, fx, fu);
+        const double *Q = Qm(par), *R = Rm(par);
+        for (int i = 0; i < NX; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < NX; ++j) s += Q[i * NX + j] * (x[j] - xref(par)[j]);
+            lx[i] = s;
+        }
+        for (int i = 0; i < NU; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < NU; ++j) s += R[i * NU + j] * (u[j] - uref(par)[j]);
+            lu[i] = s;
+        }
+        for (int i = 0; i < NX * NX; ++i) lxx[i] = Q[i];
+        for (int i = 0; i < NU * NU; ++i) luu[i] = R[i];
+        for (int i = 0; i < NU * NX; ++i) lux[i] = 0.0;
+    }
+    // acrobot.py:163-166
+    __device__ static void final(const double* par, const double* x, double* Vx, double* Vxx)
+    {
+        const double* W = Qf(par);
+        for (int i = 0; i < NX; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < NX; ++j) s += W[i * NX + j] * (x[j] - xref(par)[j]);
+            Vx[i] = s;
+        }
+        for (int i = 0; i < NX * NX; ++i) Vxx[i] = W[i];
+    }
+    __device__ static void diff_state(const double*, const double* s, const double* r, double* dx)
+    {
+        for (int i = 0; i < NX; ++i) dx[i] = s[i] - r[i];
+    }
+};
+
+using AcrobotModel = QuadraticRK4Model<4, 1, true, acrobot_gen_xdot, acrobot_gen_xdot_jac>;
+using QuadEAModel = QuadraticRK4Model<12, 4, false, quad_ea_gen_xdot, quad_ea_gen_xdot_jac>;
+
+// ------------------------------------ quaternion quadrotor (Quadrotor_Quat.py)
+// parameter block: [dt, qdiag(12), qfdiag(12), rdiag(4), xref(13), uref(4)]
+struct QuadQuatModel {
+    static constexpr int NX = 13, NU = 4, NDX = 12, NPAR = 1 + 12 + 12 + 4 + 13 + 4;
+    static constexpr bool UNROLL = false;
+    __device__ static const double* qd(const double* p) { return p + 1; }
+    __device__ static const double* qfd(const double* p) { return p + 13; }
+    __device__ static const double* rd(const double* p) { return p + 25; }
+    __device__ static const double* xref(const double* p) { return p + 29; }
+    __device__ static const double* uref(const double* p) { return p + 42; }
+
+    // generated cost functions take w = [xref(13), uref(4), qdiag(12), rdiag(4)]
+    __device__ static void weights(const double* par, bool fin, double* w)
+    {
+        for (int i = 0; i < 13; ++i) w[i] = xref(par)[i];
+        for (int i = 0; i < 4; ++i) w[13 + i] = uref(par)[i];
+        const double* q = fin ? qfd(par) : qd(par);
+        for (int i = 0; i < 12; ++i) w[17 + i] = q[i];
+        for (int i = 0; i < 4; ++i) w[29 + i] = rd(par)[i];
+    }
+    __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
+    {
+        rk4_step<13, quad_quat_gen_xdot>(par[0], x, u, xn);
+    }
+    __device__ static double cost_stage(const double* par, const double* x, const double* u)
+    {
+        double w[33], c;
+        weights(par, false, w);
+        quad_quat_gen_cost(w, x, u, &c);
+        return c;
+    }
+    __device__ static double cost_final(const double* par, const double* x)
+    {
+        double w[33], c;
+        weights(par, true, w);
+        quad_quat_gen_cost(w, x, uref(par), &c);   // u = uref: the action term vanishes (Quadrotor_Quat.py:153)
+        return c;
+    }
+    // The state Jacobian Gx = blkdiag(G(q)[4x3], I9) (Quadrotor_Quat.py:142-144)
+    // is applied block-wise: only the quaternion rows/columns need arithmetic.
+    //   out[12 x C] = Gx' * in[13 x C]
+    template <int C>
+    __device__ static void projT_left(const double* G, const double* in, double* out)
+    {
+        for (int j = 0; j < C; ++j) {
+            for (int i = 0; i < 3; ++i) {
+                double s = 0.0;
+                for (int t = 0; t < 4; ++t) s += G[t * 3 + i] * in[t * C + j];
+                out[i * C + j] = s;
+            }
+            for (int i = 0; i < 9; ++i) out[(3 + i) * C + j] = in[(4 + i) * C + j];
+        }
+    }
+    //   out[R x 12] = in[R x 13] * Gx
+    template <int R>
+    __device__ static void proj_right(const double* G, const double* in, double* out)
+    {
+        for (int r = 0; r < R; ++r) {
+            for (int j = 0; j < 3; ++j) {
+                double s = 0.0;
+                for (int t = 0; t < 4; ++t) s += in[r * 13 + t] * G[t * 3 + j];
+                out[r * 12 + j] = s;
+            }
+            for (int j = 0; j < 9; ++j) out[r * 12 + 3 + j] = in[r * 13 + 4 + j];
+        }
+    }
+    // Quadrotor_Quat.py:231-238 (f_x = G'AG, f_u = G'B), :248-257, :267-275
+    __device__ static void stage(const double* par, const double* x, const double* u, double* lx, double* lu,
+                                 double* lxx, double* lux, double* luu, double* fx, double* fu)
+    {
+        double w[33], G[12];
+        double l13[13], l13x13[169], T[12 * 13];
+        weights(par, false, w);
+        quad_quat_gen_G(x, G);
+        quad_quat_gen_cost_derivs(w, x, u, l13, lu, l13x13);
+        proj_right<1>(G, l13, lx);                 // (l_x G)
+        projT_left<13>(G, l13x13, T);              // G' l_xx       [12 x 13]
+        proj_right<12>(G, T, lxx);                 // (G' l_xx) G   [12 x 12]
+        for (int i = 0; i < 4 * 12; ++i) lux[i] = 0.0;   // l_ux = 0, so l_ux G = 0
+        for (int i = 0; i < 16; ++i) luu[i] = 0.0;
+        for (int i = 0; i < 4; ++i) luu[i * 4 + i] = rd(par)[i];
+        {
+            double A[169], B[52];
+            rk4_jac<13, 4, quad_quat_gen_xdot_jac>(par[0], x, u, A, B);
+            projT_left<13>(G, A, T);               // G' A
+            proj_right<12>(G, T, fx);              // G' A G
+            projT_left<4>(G, B, fu);               // G' B
+        }
+    }
+    // Quadrotor_Quat.py:259-265
+    __device__ static void final(const double* par, const double* x, double* Vx, double* Vxx)
+    {
+        double w[33], G[12], v13[13], vu[4], v13x13[169], T[12 * 13];
+        weights(par, true, w);
+        quad_quat_gen_G(x, G);
+        quad_quat_gen_cost_derivs(w, x, uref(par), v13, vu, v13x13);
+        projT_left<13>(G, v13x13, T);
+        proj_right<12>(G, T, Vxx);
+        proj_right<1>(G, v13, Vx);
+    }
+    // Quadrotor_Quat.py:218-228: G(state)' (state - ref)
+    __device__ static void diff_state(const double*, const double* s, const double* r, double* dx)
+    {
+        double G[12], e[13];
+        quad_quat_gen_G(s, G);
+        for (int i = 0; i < 13; ++i) e[i] = s[i] - r[i];
+        projT_left<1>(G, e, dx);
+    }
+};
+
+}  // namespace ilqr

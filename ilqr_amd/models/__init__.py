@@ -1,0 +1,7 @@
+from .model import Model
+from .car import CarModel
+from .acrobot import Acrobot2DModel
+from .Quadrotor_EA import QuadrotorEAModel
+from .Quadrotor_Quat import QuadrotorQuatModel
+
+__all__ = ["Model", "CarModel", "Acrobot2DModel", "QuadrotorEAModel", "QuadrotorQuatModel"]

@@ -1,0 +1,131 @@
+/*
+ * libilqr_hip -- batched iLQR on AMD Instinct MI355X (gfx950), C ABI.
+ *
+ * Every entry point is a drop-in for one piece of the reference's Python
+ * solver, computed for B independent trajectories at once.  All pointers are
+ * DEVICE pointers unless a comment says "host".  All floating-point data is
+ * IEEE fp64.  No entry point throws; each returns 0 on success or a negative
+ * ILQR_E_* code, and ilqr_last_error() gives a message for the calling thread.
+ *
+ * Data layout ("strided structure of arrays"): a per-trajectory vector field
+ * with C components is stored as field[c * stride + b] for trajectory b, and a
+ * trajectory of T such vectors as field[(k * C + c) * stride + b].  `stride`
+ * is the number of trajectories the buffers were allocated for (>= B), so
+ * consecutive lanes of a wavefront touch consecutive doubles.
+ */
+#ifndef ILQR_HIP_H
+#define ILQR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* plant models; parameter block layouts (doubles, device memory):
+ *   CAR        [r, v_target]                               control/models/car.py:55-61
+ *   ACROBOT    [dt, Q(4x4), Qf(4x4), R(1x1), xref(4), uref(1)]      control/models/acrobot.py:6-19,101-103
+ *   QUAD_EA    [dt, Q(12x12), Qf(12x12), R(4x4), xref(12), uref(4)] control/models/Quadrotor_EA.py:23-43,157-159
+ *   QUAD_QUAT  [dt, qdiag(12), qfdiag(12), rdiag(4), xref(13), uref(4)]  control/models/Quadrotor_Quat.py:39-59,178-180
+ *              (diagonal weights only)
+ * matrices are row-major. */
+enum { ILQR_MODEL_CAR = 0, ILQR_MODEL_ACROBOT = 1, ILQR_MODEL_QUAD_EA = 2, ILQR_MODEL_QUAD_QUAT = 3 };
+
+/* why a solve returned: the three ways out of the loop in
+ * control/iLQRController.py:43-51, and the numpy.linalg.LinAlgError that
+ * np.linalg.eigvals (non-finite Q, :110) or np.linalg.inv (singular Q_uu, :126) raise. */
+enum { ILQR_EXIT_DTOL = 0, ILQR_EXIT_SMALL_DELTAJ = 1, ILQR_EXIT_MAXITER = 2, ILQR_EXIT_LINALG = 3 };
+
+enum {
+    ILQR_OK = 0,
+    ILQR_E_BADARG = -1,    /* null pointer, unknown model, N < 2, B < 1, stride < B ... */
+    ILQR_E_WORKSPACE = -2, /* workspace missing or too small */
+    ILQR_E_HIP = -3,       /* a HIP runtime call failed */
+    ILQR_E_NODEVICE = -4   /* no gfx950 device visible */
+};
+
+/* replaces the constructor arguments of control/iLQRController.py:8-20 plus the plant's own parameters */
+typedef struct {
+    int32_t model_id;     /* ILQR_MODEL_* */
+    int32_t N;            /* knot points; S = N-1 stages */
+    int32_t max_iter;
+    int32_t max_ls;       /* max_linesearch_iters */
+    double d_tol;
+    int64_t B;            /* trajectories in this call */
+    int64_t stride;       /* allocation stride of every strided buffer, >= B */
+    const double *params; /* device: parameter block of the model */
+    int32_t trace_len;    /* rows of the optional per-iteration traces (0 = none) */
+    int32_t flags;        /* ILQR_FLAG_* */
+} ilqr_problem;
+
+enum {
+    ILQR_FLAG_NONE = 0,
+    ILQR_FLAG_PARALLEL_LS = 1 /* evaluate the backtracking alphas of a failed first step side by side */
+};
+
+/* per-trajectory results; any pointer may be NULL.  Arrays are [B] (index b),
+ * traces are [trace_len][stride] (index it * stride + b). */
+typedef struct {
+    double *J0;          /* cost of the initial rollout            (iLQRController.py:32) */
+    double *J;           /* the solver's J at return               (iLQRController.py:79) */
+    double *dmax;        /* max_k |d_k|_2 at return                (iLQRController.py:43) */
+    double *max_abs_q;   /* largest |Q_ij| met in any backward stage (conditioning flag) */
+    int32_t *iters;      /* backward passes started                (iLQRController.py:46) */
+    int32_t *status;     /* ILQR_EXIT_* */
+    int32_t *regu_rounds;/* total regularisation rounds            (iLQRController.py:110-115) */
+    int32_t *ls_total;   /* total forward-pass evaluations         (iLQRController.py:61-64) */
+    int32_t *ls_evals;   /* trace: line-search evaluations of iteration it */
+    uint8_t *accepted;   /* trace: 1 if the search of iteration it was accepted (:69) */
+    double *J_trace;     /* trace: Jn after the search of iteration it (:79) */
+    double *deltaJ_trace;/* trace: expected reduction of iteration it (:49) */
+} ilqr_outputs;
+
+/* model.get_dims(): control/models/model.py:9-10.  npar = doubles in the parameter block. */
+int ilqr_model_info(int32_t model_id, int32_t *nx, int32_t *nu, int32_t *ndx, int32_t *npar);
+
+/* bytes of device workspace ilqr_solve_batch needs for this problem */
+size_t ilqr_workspace_bytes(const ilqr_problem *p);
+
+/* iLQR.run_ilqr for B trajectories: control/iLQRController.py:26-84 with
+ * _forward_pass (:87-96), _backward_pass (:98-123), _gains (:125-129),
+ * _V_terms (:131-134), _expected_cost_reduction (:136-137), _full_hessian
+ * (:139-147), Model.rollout / cost_trj / Q_terms / CalcDifferentialState
+ * (control/models/model.py:15-53) and the plant's stage/final derivatives.
+ *   x0 [nx][stride]        in
+ *   u  [N-1][nu][stride]   in: initial controls; out: optimised controls (in place, like :72)
+ *   x  [N][nx][stride]     out: optimised states (:71, :84)
+ * `stream` is a hipStream_t (NULL = default stream).  The call only enqueues work. */
+int ilqr_solve_batch(const ilqr_problem *p, const double *x0, double *u, double *x, const ilqr_outputs *out,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Model.rollout + Model.cost_trj (control/models/model.py:15-20, :31-37 and
+ * the plants' cost_trj overrides): x [N][nx][stride] out, J [B] out. */
+int ilqr_rollout_cost(const ilqr_problem *p, const double *x0, const double *u, double *x, double *J, void *stream);
+
+/* One evaluation per trajectory of the plant interface of control/models/model.py:
+ * discrete_dynamics (:12), _cost_stage (:25), _cost_final (:28), stage (:39), final (:42).
+ *   xs [nx][stride], us [nu][stride] in; any output may be NULL:
+ *   xn [nx][stride]; cs, cf [B];
+ *   l_x [ndx] l_u [nu] l_xx [ndx*ndx] l_ux [nu*ndx] l_uu [nu*nu] f_x [ndx*ndx] f_u [ndx*nu]  (x stride, row-major)
+ *   V_x [ndx], V_xx [ndx*ndx]
+ * For QUAD_QUAT the cost derivatives are returned already projected on the
+ * 12-dim error state (l_x G, G' l_xx G, l_ux G: Quadrotor_Quat.py:267-275). */
+int ilqr_model_eval(const ilqr_problem *p, const double *xs, const double *us, double *xn, double *cs, double *cf,
+                    double *l_x, double *l_u, double *l_xx, double *l_ux, double *l_uu, double *f_x, double *f_u,
+                    double *V_x, double *V_xx, void *stream);
+
+/* Receding-horizon helper (control/QuadrotorControllers.py:72-76, :185-188;
+ * control/AcrobotControllers.py:60-63): x0 <- discrete_dynamics(x0, u[0]) and
+ * u[:-1] <- u[1:] (last row kept), in place, for B trajectories. */
+int ilqr_mpc_advance(const ilqr_problem *p, double *x0, double *u, void *stream);
+
+/* message for the last error on the calling thread (host pointer, never NULL) */
+const char *ilqr_last_error(void);
+
+/* library version string (host pointer) */
+const char *ilqr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,130 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of the CPU checker (oracle/ilqr_oracle.c).
+
+Only tests/, the smoke check and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libilqr_oracle.so")
+
+TRACE_MAX = 64
+MODEL_IDS = dict(car=0, acrobot=1, quad_ea=2, quad_quat=3)
+EXIT_NAMES = {0: "d_tol", 1: "deltaJ<1", 2: "max_iter", 3: "linalg_error"}
+
+INFO_DTYPE = np.dtype([
+    ("J0", "<f8"), ("J_last", "<f8"), ("dmax", "<f8"), ("max_abs_q", "<f8"),
+    ("J", "<f8", (TRACE_MAX,)), ("deltaJ", "<f8", (TRACE_MAX,)),
+    ("ls_evals", "<i4", (TRACE_MAX,)), ("accepted", "u1", (TRACE_MAX,)),
+    ("iters", "<i4"), ("status", "<i4"), ("regu_rounds", "<i4"), ("ls_total", "<i4"),
+], align=True)
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        L.ilqr_oracle_solve_batch.restype = C.c_int
+        L.ilqr_oracle_solve_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_long,
+                                              dp, dp, dp, C.c_void_p, C.c_int]
+        L.ilqr_oracle_model_dims.restype = None
+        L.ilqr_oracle_model_dims.argtypes = [C.c_int] + [C.POINTER(C.c_int)] * 4
+        L.ilqr_oracle_eval.restype = C.c_int
+        L.ilqr_oracle_eval.argtypes = [C.c_int] + [dp] * 15
+        L.ilqr_oracle_has_negative_eig.restype = C.c_int
+        L.ilqr_oracle_has_negative_eig.argtypes = [dp, C.c_int, dp]
+        L.ilqr_oracle_unit_qterms.restype = None
+        L.ilqr_oracle_unit_qterms.argtypes = [C.c_int, C.c_int] + [dp] * 14
+        L.ilqr_oracle_unit_gains_vterms.restype = C.c_int
+        L.ilqr_oracle_unit_gains_vterms.argtypes = [C.c_int, C.c_int] + [dp] * 10
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def dims(model):
+    mid = MODEL_IDS[model] if isinstance(model, str) else model
+    v = [C.c_int() for _ in range(4)]
+    lib().ilqr_oracle_model_dims(mid, *[C.byref(x) for x in v])
+    return tuple(x.value for x in v)
+
+
+def info_size():
+    return INFO_DTYPE.itemsize
+
+
+def solve_batch(model, par, N, max_iter, max_ls, d_tol, x0, u, nthreads=0):
+    """x0[B,nx], u[B,N-1,nu] (not modified) -> dict(x[B,N,nx], u[B,N-1,nu], info structured array)."""
+    mid = MODEL_IDS[model] if isinstance(model, str) else model
+    nx, nu, ndx, npar = dims(mid)
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    assert par.size == npar, (par.size, npar)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, nx)
+    B = x0.shape[0]
+    u = np.array(u, dtype=np.float64, order="C").reshape(B, N - 1, nu)
+    x = np.zeros((B, N, nx))
+    info = np.zeros(B, dtype=INFO_DTYPE)
+    if nthreads <= 0:
+        nthreads = len(os.sched_getaffinity(0))
+    rc = lib().ilqr_oracle_solve_batch(mid, _p(par), N, max_iter, max_ls, float(d_tol), B, _p(x0), _p(u), _p(x),
+                                       info.ctypes.data_as(C.c_void_p), nthreads)
+    assert rc == 0
+    return dict(x=x, u=u, info=info)
+
+
+def eval_point(model, par, x, u):
+    mid = MODEL_IDS[model] if isinstance(model, str) else model
+    nx, nu, ndx, npar = dims(mid)
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    out = dict(xn=np.zeros(nx), cs=np.zeros(1), cf=np.zeros(1), l_x=np.zeros(nx), l_u=np.zeros(nu),
+               l_xx=np.zeros((nx, nx)), l_ux=np.zeros((nu, nx)), l_uu=np.zeros((nu, nu)),
+               f_x=np.zeros((ndx, ndx)), f_u=np.zeros((ndx, nu)), V_x=np.zeros(ndx), V_xx=np.zeros((ndx, ndx)))
+    rc = lib().ilqr_oracle_eval(mid, _p(par), _p(x), _p(u), *[_p(out[k]) for k in
+                                ("xn", "cs", "cf", "l_x", "l_u", "l_xx", "l_ux", "l_uu", "f_x", "f_u", "V_x", "V_xx")])
+    assert rc == 0
+    out["cs"] = float(out["cs"][0]); out["cf"] = float(out["cf"][0])
+    return out
+
+
+def has_negative_eig(Q):
+    Q = np.ascontiguousarray(Q, dtype=np.float64)
+    W = np.zeros_like(Q)
+    return lib().ilqr_oracle_has_negative_eig(_p(Q), Q.shape[0], _p(W))
+
+
+# parameter-block packers (layouts documented in oracle/ilqr_oracle.h)
+def pack_car(r, v_target):
+    return np.array([r, v_target], dtype=np.float64)
+
+
+def pack_quadratic(dt, Q, Qf, R, xref, uref):
+    return np.concatenate([[dt], np.asarray(Q, float).ravel(), np.asarray(Qf, float).ravel(),
+                           np.asarray(R, float).ravel(), np.asarray(xref, float).ravel(),
+                           np.asarray(uref, float).ravel()])
+
+
+def pack_quat(dt, Q, Qf, R, xref, uref):
+    return np.concatenate([[dt], np.diag(Q), np.diag(Qf), np.diag(R), np.asarray(xref, float).ravel(),
+                           np.asarray(uref, float).ravel()]).astype(np.float64)

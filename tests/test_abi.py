@@ -1,0 +1,86 @@
+"""The C-ABI library: loads, exports every symbol include/ilqr_hip.h declares, and validates
+arguments on the host side (no kernel is launched here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "ilqr_hip.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from ilqr_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    return _lib.lib()
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ilqr_[a-z_]+)\s*\(", src)))
+
+
+def test_header_functions_are_exported(L):
+    names = declared_functions()
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/ilqr_hip.h but not exported"
+    from ilqr_amd import _lib
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_model_info(L):
+    from ilqr_amd import _lib
+    assert _lib.model_info(0) == (5, 2, 5, 2)
+    assert _lib.model_info(1) == (4, 1, 4, 1 + 16 + 16 + 1 + 4 + 1)
+    assert _lib.model_info(2) == (12, 4, 12, 1 + 144 + 144 + 16 + 12 + 4)
+    assert _lib.model_info(3) == (13, 4, 12, 46)
+    assert L.ilqr_model_info(9, None, None, None, None) == -1
+    assert b"model" in L.ilqr_last_error()
+
+
+def test_struct_layout_matches_header():
+    from ilqr_amd import _lib
+    assert C.sizeof(_lib.Problem) == 56     # 4 int32, double, 2 int64, pointer, 2 int32
+    assert C.sizeof(_lib.Outputs) == 12 * 8
+
+
+def test_argument_validation_and_workspace(L):
+    from ilqr_amd import _lib
+    fake = C.c_void_p(256)   # never dereferenced: validation fails first
+    def prob(**kw):
+        d = dict(model_id=0, N=40, max_iter=50, max_ls=20, d_tol=1e-3, B=1024, stride=1024, params=fake,
+                 trace_len=0, flags=0)
+        d.update(kw)
+        return _lib.Problem(**d)
+    p = prob()
+    S, n, m, nx = 39, 5, 2, 5
+    need = 8 * 1024 * (S * m + S * m * n + 40 * nx + S * m)
+    assert L.ilqr_workspace_bytes(C.byref(p)) >= need
+    assert L.ilqr_workspace_bytes(C.byref(prob(N=1))) == 0
+    for bad in (prob(N=1), prob(B=0), prob(stride=8), prob(model_id=7), prob(params=None)):
+        assert L.ilqr_solve_batch(C.byref(bad), fake, fake, fake, None, fake, 1 << 40, None) == -1
+    assert L.ilqr_solve_batch(C.byref(p), None, fake, fake, None, fake, 1 << 40, None) == -1
+    assert L.ilqr_solve_batch(C.byref(p), fake, fake, fake, None, fake, 16, None) == -2
+    assert L.ilqr_solve_batch(C.byref(p), fake, fake, fake, None, None, 0, None) == -2
+    assert L.ilqr_version().startswith(b"ilqr_hip")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ilqr_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.LibraryMissing):
+        _lib.lib()
+
+
+def test_no_cpu_device_path():
+    from ilqr_amd.batch import BatchSolver
+    with pytest.raises(RuntimeError):
+        BatchSolver(0, [2.0, 2.0], 40, 50, device="cpu")

@@ -1,0 +1,261 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors of the reference
+solver and against the CPU checker on seeded batches.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from helpers import compare_to_golden, model_key, rel_traj, tolerance
+
+pytestmark = pytest.mark.gpu
+MID = dict(car=0, acrobot=1, quad_ea=2, quad_quat=3)
+
+
+@pytest.fixture(scope="module")
+def torch_gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    from ilqr_amd import _lib
+    _lib.lib()          # fails loudly if libilqr_hip.so is missing
+    return torch
+
+
+def _solve(g_or_cfg, x0, u0, trace=64):
+    from ilqr_amd.batch import BatchSolver
+    c = g_or_cfg
+    s = BatchSolver(MID[str(c["model"])], c["par"], int(c["N"]), int(c["max_iter"]), int(c["max_ls"]),
+                    float(c["d_tol"]), trace_len=trace)
+    r = s.solve(x0, u0)
+    cp = lambda t: t.cpu().numpy()
+    return dict(x=cp(r.x), u=cp(r.u), J=cp(r.J), J0=cp(r.J0), iters=cp(r.iters), status=cp(r.status),
+                regu=cp(r.regu_rounds), ls_total=cp(r.ls_total), ls=cp(r.traces["ls_evals"]),
+                acc=cp(r.traces["accepted"]), maxq=cp(r.max_abs_q), dmax=cp(r.dmax))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_hip_matches_reference_golden(torch_gpu, name):
+    g = load_golden(name)
+    r = _solve(g, g["x0"], g["u_init"])
+    compare_to_golden(g, r["x"], r["u"], r["J"], r["iters"], r["status"], r["ls"], r["acc"], r["regu"], J0=r["J0"],
+                      label=name)
+
+
+def _car_box(rng, B):
+    return np.column_stack([rng.uniform(-4, 4, B), rng.uniform(-4, 4, B), rng.uniform(-np.pi, np.pi, B),
+                            rng.uniform(0, 3, B), rng.uniform(-0.3, 0.3, B)])
+
+
+def _cfg(oracle, kind):
+    Q = np.diag([10.0] * 6 + [1.0] * 6); Qf = np.diag([500.0] * 3 + [100.0] * 3 + [20.0] * 6); R = np.diag([0.02] * 4)
+    if kind == "car":
+        return dict(model="car", par=oracle.pack_car(2.0, 2.0), N=40, max_iter=50, max_ls=20, d_tol=1e-3)
+    if kind == "acrobot":
+        par = oracle.pack_quadratic(0.05, np.diag([1, 1, .1, .1]), 100.0 * np.eye(4), [[0.01]], [np.pi, 0, 0, 0], [0.0])
+        return dict(model="acrobot", par=par, N=100, max_iter=20, max_ls=10, d_tol=1e-3)
+    if kind == "quad_ea":
+        xref = np.zeros(12); xref[2] = 1.0
+        return dict(model="quad_ea", par=oracle.pack_quadratic(0.01, Q, Qf, R, xref, np.zeros(4)), N=30, max_iter=20,
+                    max_ls=10, d_tol=5e-4)
+    xref = np.zeros(13); xref[0] = 1.0; xref[6] = 1.0
+    return dict(model="quad_quat", par=oracle.pack_quat(0.01, Q, Qf, R, xref, np.zeros(4)), N=30, max_iter=20,
+                max_ls=10, d_tol=5e-4)
+
+
+def _inputs(kind, rng, B, N):
+    if kind == "car":
+        return _car_box(rng, B), rng.standard_normal((B, N - 1, 2)) * 1e-4
+    if kind == "acrobot":
+        x0 = np.column_stack([rng.uniform(-np.pi, np.pi, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B),
+                              rng.uniform(-1, 1, B)])
+        return x0, rng.standard_normal((B, N - 1, 1))
+    if kind == "quad_ea":
+        x0 = np.zeros((B, 12)); x0[:, 2] = 0.8; x0[:, 3:6] = 0.5 * rng.standard_normal((B, 3))
+        return x0, 1.9 + 0.5 * rng.standard_normal((B, N - 1, 4))
+    x0 = np.zeros((B, 13)); x0[:, 6] = 0.8
+    q = np.column_stack([np.ones(B), 0.25 * rng.standard_normal((B, 3))])
+    x0[:, :4] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    return x0, 1.9 + 0.5 * rng.standard_normal((B, N - 1, 4))
+
+
+@pytest.mark.parametrize("kind,B", [("car", 4096), ("acrobot", 512), ("quad_ea", 256), ("quad_quat", 256)])
+def test_hip_matches_checker_on_seeded_batch(torch_gpu, oracle, kind, B):
+    """Same seeded inputs through the HIP path and the CPU checker.  A trajectory is compared tightly when the
+    checker reproduces itself under a 1e-14 input perturbation (the fixtures' `stable`/`sens` rule)."""
+    rng = np.random.default_rng(dict(car=1234, acrobot=2, quad_ea=3, quad_quat=4)[kind])
+    c = _cfg(oracle, kind)
+    x0, u0 = _inputs(kind, rng, B, c["N"])
+    ref = oracle.solve_batch(kind, c["par"], c["N"], c["max_iter"], c["max_ls"], c["d_tol"], x0, u0)
+    sgn = np.random.default_rng(1).choice([-1.0, 1.0], size=u0.shape)
+    sgx = np.random.default_rng(2).choice([-1.0, 1.0], size=x0.shape)
+    per = oracle.solve_batch(kind, c["par"], c["N"], c["max_iter"], c["max_ls"], c["d_tol"], x0 * (1 + 1e-14 * sgx),
+                             u0 * (1 + 1e-14 * sgn))
+    i, j = ref["info"], per["info"]
+    same_self = ((i["iters"] == j["iters"]) & (i["status"] == j["status"]) & (i["regu_rounds"] == j["regu_rounds"])
+                 & (i["ls_evals"] == j["ls_evals"]).all(1))
+    sens = np.maximum(rel_traj(per["x"], ref["x"]), rel_traj(per["u"], ref["u"]))
+    sens = np.where(np.isfinite(sens), sens, np.inf)
+    stable = same_self & (sens <= 1e-8) & (i["status"] != 3)
+    r = _solve(c, x0, u0)
+    lin = (i["status"] == 3) & (i["regu_rounds"] == 0)
+    assert np.array_equal(r["status"][lin], i["status"][lin])
+    same = ((r["iters"] == i["iters"]) & (r["status"] == i["status"]) & (r["regu"] == i["regu_rounds"])
+            & (r["ls"] == i["ls_evals"]).all(1) & (r["acc"] == i["accepted"]).all(1))
+    assert same[stable].all(), f"{kind}: {int((~same & stable).sum())} stable trajectories differ in decisions"
+    rx, ru = rel_traj(r["x"], ref["x"]), rel_traj(r["u"], ref["u"])
+    tol = tolerance(sens, i["status"])
+    assert (rx[stable] <= tol[stable]).all() and (ru[stable] <= tol[stable]).all(), (rx[stable].max(), ru[stable].max())
+    Jr = i["J_last"]
+    fin = stable & np.isfinite(Jr)
+    assert (np.abs(r["J"][fin] - Jr[fin]) <= tol[fin] * np.abs(Jr[fin])).all()
+    assert stable.mean() > (0.5 if kind == "car" else 0.3), f"too few comparable trajectories: {stable.mean():.2f}"
+    # the statistics of the whole batch (ill-conditioned solves included) stay close
+    assert abs(r["iters"].mean() - i["iters"].mean()) <= 0.15 * i["iters"].mean() + 0.5
+
+
+@pytest.mark.parametrize("kind", ["car", "acrobot", "quad_ea", "quad_quat"])
+def test_model_eval_matches_checker(torch_gpu, oracle, kind):
+    """discrete_dynamics, _cost_stage, _cost_final, stage, final at random points (fp64, rtol 1e-10)."""
+    from ilqr_amd.batch import BatchSolver
+    rng = np.random.default_rng(11)
+    c = _cfg(oracle, kind)
+    B = 128
+    x0, u0 = _inputs(kind, rng, B, 3)
+    xs = x0 + 0.1 * rng.standard_normal(x0.shape)
+    us = u0[:, 0, :]
+    s = BatchSolver(MID[kind], c["par"], 3, 1)
+    out = {k: v.cpu().numpy() for k, v in s.model_eval(xs, us).items()}
+    for b in range(B):
+        e = oracle.eval_point(kind, c["par"], xs[b], us[b])
+        if kind == "quad_quat":
+            # the HIP path returns the cost derivatives already projected on the error state
+            Gx = np.zeros((13, 12)); q = xs[b, :4] / np.linalg.norm(xs[b, :4]); w, x, y, z = q
+            Gx[:4, :3] = [[-x, -y, -z], [w, -z, y], [z, w, -x], [-y, x, w]]; Gx[4:, 3:] = np.eye(9)
+            e["l_x"] = e["l_x"] @ Gx; e["l_xx"] = Gx.T @ e["l_xx"] @ Gx; e["l_ux"] = e["l_ux"] @ Gx
+        for k in ("xn", "cs", "cf", "l_x", "l_u", "l_xx", "l_ux", "l_uu", "f_x", "f_u", "V_x", "V_xx"):
+            ref = np.asarray(e[k], dtype=np.float64)
+            got = out[k][b].reshape(ref.shape)
+            sc = max(1.0, np.abs(ref).max())
+            assert np.allclose(got, ref, rtol=1e-10, atol=1e-11 * sc), (kind, k, b, np.abs(got - ref).max())
+
+
+def test_rollout_cost_and_final_state_is_a_rollout(torch_gpu, oracle):
+    """Property at the headline batch size: the returned x is bit-for-bit the rollout of the returned u
+    (iLQRController.py:63, :71-72), x[0] == x0, iters <= max_iter, J == cost of (x, u) after an accepted search."""
+    from ilqr_amd.batch import BatchSolver
+    rng = np.random.default_rng(1234)
+    B = 1 << 16
+    c = _cfg(oracle, "car")
+    x0, u0 = _car_box(rng, B), rng.standard_normal((B, 39, 2)) * 1e-4
+    s = BatchSolver(0, c["par"], 40, 50, 20, 1e-3, trace_len=50)
+    r = s.solve(x0, u0)
+    x, u = r.x.cpu().numpy(), r.u.cpu().numpy()
+    st, it = r.status.cpu().numpy(), r.iters.cpu().numpy()
+    assert set(np.unique(st)) <= {0, 1, 2, 3}
+    assert it.max() <= 50 and it.min() >= 1
+    assert np.array_equal(x[:, 0, :], x0)
+    xr, Jr = s.rollout_cost(x0, u)
+    ok = st != 3
+    assert np.array_equal(xr.cpu().numpy()[ok], x[ok])
+    # after an accepted last search (or none abandoned), J is the cost of the returned trajectory
+    acc, ls = r.traces["accepted"].cpu().numpy(), r.traces["ls_evals"].cpu().numpy()
+    searched = ls > 0
+    clean = ok & ((acc == 1) | ~searched).all(1)
+    J = r.J.cpu().numpy()
+    assert np.array_equal(Jr.cpu().numpy()[clean], J[clean])
+    assert (J[clean] <= r.J0.cpu().numpy()[clean]).all()
+    assert clean.mean() > 0.5
+
+
+def test_same_batch_is_bitwise_reproducible_and_shards_agree(torch_gpu, oracle):
+    """Trajectories are independent: solving a batch twice, or in two halves, gives bit-identical results."""
+    rng = np.random.default_rng(3)
+    B = 2048
+    c = _cfg(oracle, "car")
+    x0, u0 = _car_box(rng, B), rng.standard_normal((B, 39, 2)) * 1e-4
+    a = _solve(c, x0, u0)
+    b = _solve(c, x0, u0)
+    for k in ("x", "u", "J", "iters", "status", "regu", "ls"):
+        assert np.array_equal(a[k], b[k], equal_nan=True) if a[k].dtype.kind == "f" else np.array_equal(a[k], b[k]), k
+    h1, h2 = _solve(c, x0[:1000], u0[:1000]), _solve(c, x0[1000:], u0[1000:])
+    for k in ("x", "u", "J", "iters", "status"):
+        whole = a[k]
+        parts = np.concatenate([h1[k], h2[k]])
+        assert np.array_equal(whole, parts, equal_nan=True) if whole.dtype.kind == "f" else np.array_equal(whole, parts), k
+
+
+def test_drop_in_single_trajectory_api(torch_gpu):
+    """control/iLQRController.py:8-24, :26, :72, :84: constructor, attributes, in-place u, fresh x, ignored kwargs."""
+    from ilqr_amd import CarModel, iLQR
+    plant = CarModel(2, 2)
+    ctl = iLQR(plant, N=40, max_iter=50, max_linesearch_iters=20, regu_init=100, min_regu=0.001, max_regu=10000)
+    assert (ctl.nx, ctl.nu, ctl.ndx, ctl.N, ctl.max_iter, ctl.max_linesearch_iters, ctl.d_tol) == (5, 2, 5, 40, 50, 20, 1e-3)
+    assert (ctl.num_ls_success, ctl.num_ls_fails, ctl.num_iters) == (0, 0, 0)
+    g = load_golden("car_readme")
+    u = g["u_init"][0].copy()
+    x, u_ret = ctl.run_ilqr(g["x0"][0], u)
+    assert u_ret is u and x.shape == (40, 5) and ctl.num_iters == 1
+    assert np.allclose(x, g["x"][0], rtol=1e-9, atol=1e-10) and np.allclose(u, g["u"][0], rtol=1e-9, atol=1e-10)
+    assert int(ctl.info.iters[0]) == 5
+    # receding-horizon protocol of Driving.ipynb cell-2: re-solve from x[1] with the carried-over u
+    m = load_golden("car_mpc50")
+    x0 = m["x0"][0].copy(); u = m["u_init"][0].copy()
+    for k in range(5):
+        assert np.allclose(x0, m["x0"][k], rtol=1e-9, atol=1e-10)
+        xk, u = ctl.run_ilqr(x0, u)
+        x0 = xk[1]
+    # LinAlgError where NumPy raises it
+    with pytest.raises(np.linalg.LinAlgError):
+        ctl.run_ilqr(g["x0"][0], np.full((39, 2), 1e155))
+    with pytest.raises(ValueError):
+        ctl.run_ilqr(g["x0"][0], np.zeros((38, 2)))
+
+
+def test_model_interface_single_point(torch_gpu, oracle):
+    """Model.discrete_dynamics/_cost_stage/_cost_final/stage/final/rollout/cost_trj/get_dims for one state."""
+    from ilqr_amd import Acrobot2DModel, CarModel, QuadrotorQuatModel
+    plant = CarModel(2.0, 2.0)
+    assert plant.get_dims() == (5, 2, 5)
+    x, u = np.array([1.0, -2.0, 0.3, 1.5, 0.1]), np.array([0.2, -0.1])
+    e = oracle.eval_point("car", oracle.pack_car(2.0, 2.0), x, u)
+    assert np.allclose(plant.discrete_dynamics(x, u), e["xn"], rtol=1e-12)
+    assert np.isclose(plant._cost_stage(x, u), e["cs"], rtol=1e-12) and np.isclose(plant._cost_final(x), e["cf"], rtol=1e-12)
+    for got, key in zip(plant.stage(x, u), ("l_x", "l_u", "l_xx", "l_ux", "l_uu", "f_x", "f_u")):
+        assert np.allclose(got, e[key], rtol=1e-10, atol=1e-12), key
+    Vx, Vxx = plant.final(x)
+    assert np.allclose(Vx, e["V_x"], rtol=1e-10) and np.allclose(Vxx, e["V_xx"], rtol=1e-10)
+    utr = np.random.default_rng(0).standard_normal((7, 2)) * 0.1
+    xtr = plant.rollout(x, utr)
+    assert xtr.shape == (8, 5) and np.allclose(xtr[1], plant.discrete_dynamics(x, utr[0]), rtol=1e-13)
+    J = plant.cost_trj(xtr, utr)
+    assert np.isclose(J, sum(plant._cost_stage(xtr[k], utr[k]) for k in range(7)) + plant._cost_final(xtr[-1]), rtol=1e-12)
+    ac = Acrobot2DModel(np.diag([1, 1, .1, .1]), 100 * np.eye(4), np.array([[0.01]]), 0.05, 10)
+    ac.set_references(np.array([np.pi, 0, 0, 0.0]), np.zeros(1))
+    par = oracle.pack_quadratic(0.05, ac.Q, ac.Qf, ac.R, ac.xref, ac.uref)
+    xa, ua = np.array([0.3, -0.2, 0.5, 0.1]), np.array([0.7])
+    ea = oracle.eval_point("acrobot", par, xa, ua)
+    assert np.allclose(ac.discrete_dynamics(xa, ua), ea["xn"], rtol=1e-12)
+    assert np.isclose(ac._cost_stage(xa, ua, ac.xref, ac.uref), ea["cs"], rtol=1e-12)
+    Q = np.diag([10.0] * 6 + [1.0] * 6)
+    qq = QuadrotorQuatModel(Q, Q, np.eye(4) * 0.02, 0.01, 10)
+    with pytest.raises(NotImplementedError):
+        QuadrotorQuatModel(np.ones((12, 12)), Q, np.eye(4), 0.01, 10)
+    s = np.zeros(13); s[0] = 1; r = np.zeros(13); r[0] = 1; r[4] = 0.5
+    assert qq.CalcDifferentialState(s, r).shape == (12,)
+
+
+def test_mpc_advance(torch_gpu, oracle):
+    """Receding-horizon step on device buffers: x0 <- f(x0, u[0]); u[:-1] <- u[1:] (QuadrotorControllers.py:72-76)."""
+    import torch
+    from ilqr_amd.batch import BatchSolver
+    rng = np.random.default_rng(5)
+    B, N = 300, 12
+    c = _cfg(oracle, "quad_quat")
+    x0, u0 = _inputs("quad_quat", rng, B, N)
+    s = BatchSolver(3, c["par"], N, 1)
+    xs = torch.as_tensor(x0).cuda().t().contiguous()
+    us = torch.as_tensor(u0).cuda().permute(1, 2, 0).contiguous()
+    s.mpc_advance(xs, us)
+    un = us.permute(2, 0, 1).cpu().numpy(); xn = xs.t().cpu().numpy()
+    assert np.array_equal(un[:, :-1], u0[:, 1:]) and np.array_equal(un[:, -1], u0[:, -1])
+    for b in range(0, B, 37):
+        e = oracle.eval_point("quad_quat", c["par"], x0[b], u0[b, 0])
+        assert np.allclose(xn[b], e["xn"], rtol=1e-12, atol=1e-13)

@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Model code generator: SymPy expressions -> straight-line C (host + gfx950 device).
+
+The reference obtains plant derivatives from symbolic / AD back-ends at run
+time (pydrake.symbolic in control/models/car.py:5-52; CasADi graphs in
+control/models/acrobot.py:35-99, Quadrotor_EA.py:57-155,
+Quadrotor_Quat.py:74-175).  Here the same expressions are differentiated once,
+offline, common sub-expressions are eliminated, and the result is printed as
+plain C functions.  Each function is declared `ILQR_HD static inline`, where
+`ILQR_HD` expands to `__host__ __device__` under hipcc and to nothing under
+gcc, so one text serves the HIP kernels and the CPU checker.
+
+The symbolic expressions are obtained by running the arithmetic in
+oracle/models_numpy.py on SymPy symbols, so the generated C and the golden
+vectors come from one statement of each model.
+
+Outputs (identical text, two homes so that the shipped library never includes
+anything from oracle/):
+    ilqr_amd/csrc/gen/<model>_gen.h
+    oracle/gen/<model>_gen.h
+plus  ilqr_amd/csrc/gen/opcounts.json  (operation counts of the emitted code;
+used for the algorithmic-flop figure of the roofline report).
+
+Usage:  python tools/gen_models.py [car acrobot quad_ea quad_quat]
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import sympy as sp
+from sympy.printing.c import C99CodePrinter
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import models_numpy as mn  # noqa: E402
+
+OUT_DIRS = [os.path.join(ROOT, "ilqr_amd", "csrc", "gen"), os.path.join(ROOT, "oracle", "gen")]
+
+
+class _Printer(C99CodePrinter):
+    """C printer that never calls pow() for the small rational powers that occur."""
+
+    def _print_Pow(self, expr):
+        b, e = expr.base, expr.exp
+        if e.is_Integer:
+            n = int(e)
+            bs = self.parenthesize(b, 1000)
+            if n == 0:
+                return "1.0"
+            mul = "*".join([bs] * abs(n))
+            return f"({mul})" if n > 0 else f"(1.0/({mul}))"
+        if e.is_Rational and e.q == 2:
+            n = int(e.p)
+            bs = self._print(b)
+            root = f"sqrt({bs})"
+            k = abs(n)
+            # b^(k/2) = b^(k//2) * sqrt(b) for odd k
+            pw = "*".join([f"({bs})"] * (k // 2) + [root])
+            return f"({pw})" if n > 0 else f"(1.0/({pw}))"
+        return super()._print_Pow(expr)
+
+    def _print_Rational(self, expr):
+        return f"({float(expr.p)!r}/{float(expr.q)!r})"
+
+    def _print_Integer(self, expr):
+        return f"{float(int(expr))!r}"
+
+    def _print_Float(self, expr):
+        return repr(float(expr))
+
+
+_P = _Printer()
+
+
+def _count_ops(exprs):
+    """Count arithmetic in a list of (already CSE'd) expressions.
+    FMA-able mul+add pairs are counted as separate mul and add (2 flops)."""
+    c = dict(add=0, mul=0, div=0, sqrt=0, sin=0, cos=0, tan=0)
+    for e in exprs:
+        for node in sp.preorder_traversal(e):
+            if isinstance(node, sp.Add):
+                c["add"] += len(node.args) - 1
+            elif isinstance(node, sp.Mul):
+                nargs = len(node.args)
+                # a*b**-1 is a division
+                ndiv = sum(1 for a in node.args if isinstance(a, sp.Pow) and a.exp.is_negative)
+                c["mul"] += max(nargs - 1 - ndiv, 0)
+                c["div"] += ndiv
+            elif isinstance(node, sp.Pow):
+                ex = node.exp
+                if ex.is_Integer:
+                    c["mul"] += abs(int(ex)) - 1
+                    # a lone reciprocal (not inside a Mul) is handled by the Mul case mostly
+                elif ex.is_Rational and ex.q == 2:
+                    c["sqrt"] += 1
+                    c["mul"] += abs(int(ex.p)) // 2
+            elif isinstance(node, sp.sin):
+                c["sin"] += 1
+            elif isinstance(node, sp.cos):
+                c["cos"] += 1
+            elif isinstance(node, sp.tan):
+                c["tan"] += 1
+    c["flops"] = sum(c.values())
+    return c
+
+
+def emit_function(name, inputs, outputs, doc):
+    """inputs: list of (cname, [symbols]); outputs: list of (cname, sympy Matrix or list).
+    Dense row-major outputs; structural zeros are written as 0.0."""
+    flat = []
+    for _, M in outputs:
+        M = sp.Matrix(M)
+        flat.extend(list(M))          # row-major
+    t0 = time.time()
+    repl, red = sp.cse(flat, symbols=sp.numbered_symbols("t"), optimizations="basic", order="none")
+    lines = []
+    args = ", ".join([f"const double* __restrict__ {n}" for n, _ in inputs] +
+                     [f"double* __restrict__ {n}" for n, _ in outputs])
+    lines.append(f"/* {doc} */")
+    lines.append(f"ILQR_HD static inline void {name}({args})")
+    lines.append("{")
+    sub = {}
+    for n, syms in inputs:
+        for i, s in enumerate(syms):
+            sub[s] = sp.Symbol(f"{n}[{i}]")
+    used = set()
+    for e in [r for _, r in repl] + red:
+        used |= e.free_symbols
+    for n, syms in inputs:
+        if not any(s in used for s in syms):
+            lines.append(f"    (void){n};")
+    for t, e in repl:
+        lines.append(f"    const double {t} = {_P.doprint(e.xreplace(sub))};")
+    k = 0
+    for n, M in outputs:
+        M = sp.Matrix(M)
+        for i in range(len(M)):
+            lines.append(f"    {n}[{i}] = {_P.doprint(red[k].xreplace(sub))};")
+            k += 1
+    lines.append("}")
+    ops = _count_ops([e for _, e in repl] + red)
+    sys.stderr.write(f"  {name}: {len(repl)} temporaries, {ops['flops']} flops, cse {time.time() - t0:.1f}s\n")
+    return "\n".join(lines) + "\n", ops
+
+
+HEADER = """/* GENERATED by tools/gen_models.py -- do not edit.
+ * {what}
+ * Dense row-major outputs.  ILQR_HD = __host__ __device__ under hipcc.
+ */
+#pragma once
+#include <math.h>
+#ifndef ILQR_HD
+#  if defined(__HIPCC__)
+#    define ILQR_HD __host__ __device__
+#  else
+#    define ILQR_HD
+#  endif
+#endif
+
+"""
+
+
+def gen_car():
+    xs = sp.symbols("x0:5", real=True)
+    us = sp.symbols("u0:2", real=True)
+    ps = sp.symbols("p0:2", real=True)   # p = [r, v_target]
+    x, u = list(xs), list(us)
+    l = mn.car_cost_stage(x, u, ps[0], ps[1])
+    lf = mn.car_cost_final(x, ps[0], ps[1])
+    f = sp.Matrix(mn.car_step(x, u))
+    lx = sp.Matrix([l]).jacobian(xs)
+    lu = sp.Matrix([l]).jacobian(us)
+    lfx = sp.Matrix([lf]).jacobian(xs)
+    ins = [("p", ps), ("x", xs), ("u", us)]
+    out = HEADER.format(what="Kinematic car: reference control/models/car.py:64-94 and its "
+                             "symbolic derivatives (car.py:5-29).  p = [r, v_target].")
+    ops = {}
+    s, ops["dyn"] = emit_function("car_gen_dynamics", ins, [("xn", f)], "x_next = xdot*dt + x, dt=0.1 (car.py:76-79)")
+    out += s
+    s, ops["cost_stage"] = emit_function("car_gen_cost_stage", ins, [("c", [l])], "stage cost (car.py:81-87)")
+    out += s
+    s, ops["cost_final"] = emit_function("car_gen_cost_final", ins[:2], [("c", [lf])], "final cost (car.py:89-94)")
+    out += s
+    s, ops["stage"] = emit_function(
+        "car_gen_stage", ins,
+        [("l_x", lx), ("l_u", lu), ("l_xx", lx.jacobian(xs)), ("l_ux", lu.jacobian(xs)),
+         ("l_uu", lu.jacobian(us)), ("f_x", f.jacobian(xs)), ("f_u", f.jacobian(us))],
+        "stage derivatives (car.py:31-44): l_x[5] l_u[2] l_xx[5x5] l_ux[2x5] l_uu[2x2] f_x[5x5] f_u[5x2]")
+    out += s
+    s, ops["final"] = emit_function("car_gen_final", ins[:2], [("V_x", lfx), ("V_xx", lfx.jacobian(xs))],
+                                    "final-cost derivatives (car.py:46-52)")
+    out += s
+    return out, ops
+
+
+def _gen_continuous(prefix, xdot, nx, nu, what):
+    xs = sp.symbols(f"x0:{nx}", real=True)
+    us = sp.symbols(f"u0:{nu}", real=True)
+    f = sp.Matrix(xdot(list(xs), list(us)))
+    A = f.jacobian(xs)
+    B = f.jacobian(us)
+    ins = [("x", xs), ("u", us)]
+    out = HEADER.format(what=what)
+    ops = {}
+    s, ops["xdot"] = emit_function(f"{prefix}_gen_xdot", ins, [("f", f)], "continuous dynamics xdot = f(x,u)")
+    out += s
+    s, ops["xdot_jac"] = emit_function(f"{prefix}_gen_xdot_jac", ins, [("f", f), ("A", A), ("B", B)],
+                                       f"f[{nx}], A = df/dx [{nx}x{nx}], B = df/du [{nx}x{nu}]")
+    out += s
+    return out, ops, (xs, us)
+
+
+def gen_acrobot():
+    out, ops, _ = _gen_continuous(
+        "acrobot", mn.acrobot_xdot, 4, 1,
+        "Acrobot: reference control/models/acrobot.py:23-72 (manipulator equation, 2x2 solve "
+        "written by Cramer's rule) and its continuous-time Jacobians (acrobot.py:90-91).")
+    return out, ops
+
+
+def gen_quad_ea():
+    out, ops, _ = _gen_continuous(
+        "quad_ea", mn.quad_ea_xdot, 12, 4,
+        "Euler-angle quadrotor: reference control/models/Quadrotor_EA.py:47-128 and its "
+        "continuous-time Jacobians (Quadrotor_EA.py:146-147).")
+    return out, ops
+
+
+def gen_quad_quat():
+    out, ops, (xs, us) = _gen_continuous(
+        "quad_quat", mn.quad_quat_xdot, 13, 4,
+        "Quaternion quadrotor: reference control/models/Quadrotor_Quat.py:63-111 with "
+        "maths/casadi_quaternions.py:5-34, continuous-time Jacobians (Quadrotor_Quat.py:130-131), "
+        "attitude Jacobian and error-state cost with its derivatives (Quadrotor_Quat.py:142-175). "
+        "w = [xref(13), uref(4), qdiag(12), rdiag(4)].")
+    xr = sp.symbols("xr0:13", real=True)
+    ur = sp.symbols("ur0:4", real=True)
+    qd = sp.symbols("qd0:12", real=True)
+    rd = sp.symbols("rd0:4", real=True)
+    w = list(xr) + list(ur) + list(qd) + list(rd)
+    G = sp.Matrix(mn.quat_attitude_jacobian(list(xs[:4])))
+    s, ops["G"] = emit_function("quad_quat_gen_G", [("x", xs)], [("G", G)],
+                                "attitude Jacobian G(q) [4x3] of the normalised quaternion "
+                                "(casadi_quaternions.py:22); the 13x12 state Jacobian is blkdiag(G, I9)")
+    out += s
+    c = mn.quat_cost(list(xs), list(us), list(xr), list(ur), list(qd), list(rd))
+    ins = [("w", w), ("x", xs), ("u", us)]
+    s, ops["cost"] = emit_function("quad_quat_gen_cost", ins, [("c", [c])],
+                                   "0.5 e'Qe + 0.5 du'R du, e = Gx(x)'(x - xref) (Quadrotor_Quat.py:150-152)")
+    out += s
+    # only the quaternion block of the state Hessian is non-trivial, but the
+    # reference differentiates the whole 13-vector, so emit dense 13x13.
+    cx = sp.Matrix([c]).jacobian(xs)
+    cu = sp.Matrix([c]).jacobian(us)
+    s, ops["cost_derivs"] = emit_function(
+        "quad_quat_gen_cost_derivs", ins,
+        [("l_x", cx), ("l_u", cu), ("l_xx", cx.jacobian(xs))],
+        "l_x[13], l_u[4], l_xx[13x13] of the cost above (Quadrotor_Quat.py:158-163); "
+        "l_ux = 0 and l_uu = diag(rd) are written by the caller")
+    out += s
+    return out, ops
+
+
+GENERATORS = dict(car=gen_car, acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat)
+
+
+def main(argv):
+    which = argv[1:] or list(GENERATORS)
+    for d in OUT_DIRS:
+        os.makedirs(d, exist_ok=True)
+    ops_path = os.path.join(OUT_DIRS[0], "opcounts.json")
+    allops = json.load(open(ops_path)) if os.path.exists(ops_path) else {}
+    for name in which:
+        sys.stderr.write(f"[gen] {name}\n")
+        text, ops = GENERATORS[name]()
+        for d in OUT_DIRS:
+            with open(os.path.join(d, f"{name}_gen.h"), "w") as fh:
+                fh.write(text)
+        allops[name] = ops
+    with open(ops_path, "w") as fh:
+        json.dump(allops, fh, indent=1, sort_keys=True)
+        fh.write("\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv)

@@ -1,0 +1,413 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/ by running the REFERENCE solver.
+
+Run in the build container only (needs the reference tree, default
+/root/reference, on disk; it is imported, never copied):
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [--only car_readme,...]
+
+What is the reference's own code here and what is not:
+  * `control.iLQRController.iLQR` and `control.models.model.Model` are imported
+    unmodified from the reference tree; every solver-level decision in the
+    fixtures (iterations, line-search evaluations, acceptance, regularisation
+    rounds, exit path, the LAPACK eigenvalue test) is theirs.
+  * The plant model files cannot be imported (pydrake / CasADi are not
+    installed), so the plants are the NumPy restatements in
+    oracle/models_numpy.py, subclassing the imported `Model`.
+Instrumentation wraps bound methods and `np.linalg.eigvals` from the outside;
+no reference file is edited.
+
+Each fixture is an .npz of plain arrays: inputs (x0, u_init, parameter block),
+outputs (x, u, J0, per-iteration J / deltaJ / ls_evals / accepted, iters,
+status, regu_rounds, max_abs_q, lam_margin) and a `stable` flag: the same solve
+repeated by the reference with x0 and u_init perturbed in the 14th digit gave
+identical decision counts and trajectories/cost within 1e-8 (`sens` holds the
+observed relative change).  Solves with stable == 0 amplify rounding noise past
+the 1e-8 parity bar inside the reference itself, so they are compared on exit
+status only.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import warnings
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("ILQR_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+TRACE = 64
+OUT = os.path.join(ROOT, "tests", "golden")
+
+_M = None
+
+
+def models():
+    global _M
+    if _M is None:
+        from control.models.model import Model
+        from oracle.models_numpy import make_models
+        _M = make_models(Model)
+    return _M
+
+
+def make_plant(spec):
+    M = models()
+    kind = spec["model"]
+    if kind == "car":
+        return M["CarModel"](spec["r"], spec["v_target"])
+    cls = dict(acrobot="Acrobot2DModel", quad_ea="QuadrotorEAModel", quad_quat="QuadrotorQuatModel")[kind]
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        p = M[cls](Q=spec["Q"], Qf=spec["Qf"], R=spec["R"], dt=spec["dt"], N=spec["N"])
+    p.set_references(spec["xref"], spec["uref"])
+    return p
+
+
+def par_block(spec):
+    from oracle import c_oracle as co
+    if spec["model"] == "car":
+        return co.pack_car(spec["r"], spec["v_target"])
+    if spec["model"] == "quad_quat":
+        return co.pack_quat(spec["dt"], spec["Q"], spec["Qf"], spec["R"], spec["xref"], spec["uref"])
+    return co.pack_quadratic(spec["dt"], spec["Q"], spec["Qf"], spec["R"], spec["xref"], spec["uref"])
+
+
+def run_reference(plant, sp, x0, u_init):
+    """One instrumented run of the reference's run_ilqr.  Returns a dict of plain values."""
+    from control.iLQRController import iLQR
+    ctl = iLQR(plant, sp["N"], sp["max_iter"], sp["max_ls"], sp["d_tol"])
+    ev = []
+    eig_stats = dict(n=0, neg=0, max_abs_q=0.0, margin=np.inf, cplx=0)
+    orig_eig = np.linalg.eigvals
+
+    def eig(Q):
+        w = orig_eig(Q)
+        eig_stats["n"] += 1
+        neg = bool(np.any(w < 0))
+        eig_stats["neg"] += neg
+        a = float(np.abs(Q).max())
+        eig_stats["max_abs_q"] = max(eig_stats["max_abs_q"], a)
+        if a > 0:
+            eig_stats["margin"] = min(eig_stats["margin"], float(np.abs(w.real).min()) / a)
+        eig_stats["cplx"] += int(np.iscomplexobj(w))
+        return w
+
+    bp, fp, ct = ctl._backward_pass, ctl._forward_pass, plant.cost_trj
+
+    def wbp(*a):
+        r = bp(*a)
+        ev.append(("bp", float(np.squeeze(r[2])), float(np.max(np.linalg.norm(r[0], axis=1)))))
+        return r
+
+    def wfp(*a):
+        ev.append(("fp", float(a[4])))
+        return fp(*a)
+
+    def wct(*a):
+        c = ct(*a)
+        ev.append(("c", float(np.squeeze(c))))
+        return c
+
+    ctl._backward_pass, ctl._forward_pass, plant.cost_trj = wbp, wfp, wct
+    np.linalg.eigvals = eig
+    u = np.array(u_init, dtype=np.float64, copy=True)
+    status = None
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                x, u2 = ctl.run_ilqr(np.array(x0, dtype=np.float64), u)
+        assert u2 is u
+        x = np.asarray(x, dtype=np.float64)
+    except np.linalg.LinAlgError:
+        status = 3
+        x = np.full((sp["N"], plant.nx), np.nan)
+    finally:
+        np.linalg.eigvals = orig_eig
+        del plant.cost_trj
+    # decode the event stream
+    J0 = ev[0][1]
+    J = np.zeros(TRACE); dJ = np.zeros(TRACE); ls = np.zeros(TRACE, np.int32); acc = np.zeros(TRACE, np.uint8)
+    iters = 0
+    Jcur = J0
+    i = 1
+    last_dJ = None
+    dmax = np.inf
+    while i < len(ev):
+        assert ev[i][0] == "bp", ev[i]
+        iters += 1
+        last_dJ = ev[i][1]
+        dmax = ev[i][2]
+        if iters <= TRACE:
+            dJ[iters - 1] = last_dJ
+        i += 1
+        n_ls = 0
+        Jn = None
+        alpha = None
+        while i < len(ev) and ev[i][0] == "fp":
+            alpha = ev[i][1]
+            Jn = ev[i + 1][1]
+            n_ls += 1
+            i += 2
+        if n_ls and iters <= TRACE:
+            ls[iters - 1] = n_ls
+            J[iters - 1] = Jn
+            acc[iters - 1] = (Jn - Jcur <= -1e-2 * alpha * last_dJ) and (n_ls < sp["max_ls"])
+        if n_ls:
+            Jcur = Jn
+    if status is None:
+        if iters and n_ls == 0:
+            status = 1            # left through `if deltaJ < 1: break` (no forward pass after the last sweep)
+        elif not (dmax > sp["d_tol"]):
+            status = 0            # the while test looks at d_tol first
+        else:
+            status = 2
+    return dict(x=x, u=u, J0=J0, J=J, deltaJ=dJ, ls_evals=ls, accepted=acc, iters=iters, status=status,
+                J_last=Jcur, dmax=dmax, regu_rounds=eig_stats["neg"], n_eig=eig_stats["n"],
+                max_abs_q=eig_stats["max_abs_q"], lam_margin=eig_stats["margin"], n_complex=eig_stats["cplx"])
+
+
+def _one(args):
+    spec, sp, x0, u0, check_stable = args
+    plant = make_plant(spec)
+    r = run_reference(plant, sp, x0, u0)
+    stable, sens = 1, 0.0
+    if check_stable:
+        # the same solve with every input perturbed in the 14th digit
+        rng = np.random.default_rng(12345)
+        up = u0 * (1.0 + 1e-14 * rng.choice([-1.0, 1.0], size=u0.shape))
+        xp = x0 * (1.0 + 1e-14 * rng.choice([-1.0, 1.0], size=x0.shape))
+        r2 = run_reference(make_plant(spec), sp, xp, up)
+        same = (r["iters"] == r2["iters"] and r["status"] == r2["status"]
+                and np.array_equal(r["ls_evals"], r2["ls_evals"]) and np.array_equal(r["accepted"], r2["accepted"])
+                and r["regu_rounds"] == r2["regu_rounds"])
+        if r["status"] != 3 and r2["status"] != 3:
+            sens = float(np.abs(r["x"] - r2["x"]).max() / max(1e-300, np.abs(r["x"]).max()))
+            sens = max(sens, float(np.abs(r["u"] - r2["u"]).max() / max(1e-300, np.abs(r["u"]).max())))
+            sens = max(sens, abs(r["J_last"] - r2["J_last"]) / max(1e-300, abs(r["J_last"])))
+            same = same and sens <= 1e-8
+        stable = int(same)
+    r["sens"] = sens
+    r["stable"] = stable
+    return r
+
+
+def run_cases(name, spec, sp, X0, U0, pool, check_stable=True, extra=None):
+    B = len(X0)
+    res = list(pool.map(_one, [(spec, sp, X0[b], U0[b], check_stable) for b in range(B)], chunksize=1))
+    out = dict(par=par_block(spec), model=np.array(spec["model"]), N=sp["N"], max_iter=sp["max_iter"],
+               max_ls=sp["max_ls"], d_tol=sp["d_tol"], x0=np.asarray(X0), u_init=np.asarray(U0))
+    for k in ("x", "u", "J", "deltaJ", "ls_evals", "accepted"):
+        out[k] = np.stack([r[k] for r in res])
+    for k in ("J0", "J_last", "dmax", "max_abs_q", "lam_margin", "sens"):
+        out[k] = np.array([r[k] for r in res], dtype=np.float64)
+    for k in ("iters", "status", "regu_rounds", "n_eig", "n_complex", "stable"):
+        out[k] = np.array([r[k] for r in res], dtype=np.int32)
+    if extra:
+        out.update(extra)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    st = out["status"]
+    print(f"[golden] {name}: B={B} iters={np.bincount(out['iters'])[:12]}... status={np.bincount(st, minlength=4)} "
+          f"stable={out['stable'].sum()}/{B} ls>1: {(out['ls_evals'] > 1).any(axis=1).sum()} "
+          f"regu>0: {(out['regu_rounds'] > 0).sum()}", flush=True)
+    return out
+
+
+# ----------------------------------------------------------------------------
+CAR = dict(model="car", r=2.0, v_target=2.0)
+CAR_SP = dict(N=40, max_iter=50, max_ls=20, d_tol=1e-3)
+
+
+def car_box(rng, B):
+    return np.column_stack([rng.uniform(-4, 4, B), rng.uniform(-4, 4, B), rng.uniform(-np.pi, np.pi, B),
+                            rng.uniform(0, 3, B), rng.uniform(-0.3, 0.3, B)])
+
+
+def acrobot_spec(N=100):
+    return dict(model="acrobot", Q=np.diag([1.0, 1.0, 0.1, 0.1]), Qf=100.0 * np.eye(4), R=np.array([[0.01]]),
+                dt=0.05, N=N, xref=np.array([np.pi, 0, 0, 0.0]), uref=np.zeros(1))
+
+
+def quad_weights():
+    Q = np.diag([10.0] * 6 + [1.0] * 6)
+    Qf = np.diag([500.0] * 3 + [100.0] * 3 + [20.0] * 6)
+    R = np.diag([0.02] * 4)
+    return Q, Qf, R
+
+
+def ea_spec(N=100):
+    Q, Qf, R = quad_weights()
+    xref = np.zeros(12); xref[2] = 1.0
+    return dict(model="quad_ea", Q=Q, Qf=Qf, R=R, dt=0.01, N=N, xref=xref, uref=np.zeros(4))
+
+
+def quat_spec(N=80):
+    Q, Qf, R = quad_weights()
+    xref = np.zeros(13); xref[0] = 1.0; xref[6] = 1.0
+    return dict(model="quad_quat", Q=Q, Qf=Qf, R=R, dt=0.01, N=N, xref=xref, uref=np.zeros(4))
+
+
+def euler_zyx_to_quat(e):
+    """unit quaternion [w,x,y,z] from ZYX Euler angles e = (yaw, pitch, roll)"""
+    cy, sy = np.cos(e[0] / 2), np.sin(e[0] / 2)
+    cp, sp_ = np.cos(e[1] / 2), np.sin(e[1] / 2)
+    cr, sr = np.cos(e[2] / 2), np.sin(e[2] / 2)
+    return np.array([cr * cp * cy + sr * sp_ * sy, sr * cp * cy - cr * sp_ * sy,
+                     cr * sp_ * cy + sr * cp * sy, cr * cp * sy - sr * sp_ * cy])
+
+
+def gen_car_readme(pool):
+    x0 = np.array([[-3.0, 1.0, -0.2, 0.0, 0.0]])
+    u0 = np.random.default_rng(0).standard_normal((1, 39, 2)) * 1e-4
+    run_cases("car_readme", CAR, CAR_SP, x0, u0, pool)
+
+
+def gen_car_mpc(pool):
+    """Driving.ipynb cell-2 protocol: 50 re-solves from x[1], u carried over without shifting."""
+    plant = make_plant(CAR)
+    x0 = np.array([-3.0, 1.0, -0.2, 0.0, 0.0])
+    u = np.random.default_rng(0).standard_normal((39, 2)) * 1e-4
+    X0, U0 = [], []
+    for _ in range(50):
+        X0.append(x0.copy()); U0.append(u.copy())
+        r = run_reference(plant, CAR_SP, x0, u)
+        u = r["u"]; x0 = r["x"][1].copy()
+    run_cases("car_mpc50", CAR, CAR_SP, np.array(X0), np.array(U0), pool)
+
+
+def gen_car_box(pool):
+    rng = np.random.default_rng(1234)
+    B = 256
+    run_cases("car_box256", CAR, CAR_SP, car_box(rng, B), rng.standard_normal((B, 39, 2)) * 1e-4, pool)
+
+
+def gen_car_adversarial(pool):
+    rng = np.random.default_rng(77)
+    B = 32
+    X0 = car_box(rng, B)
+    # large random controls: forces backtracking and regularisation
+    run_cases("car_bigu", CAR, CAR_SP, X0, rng.standard_normal((B, 39, 2)) * 2.0, pool)
+    # max_ls = 1 / 2: every search is abandoned / only alpha=1 can be accepted
+    run_cases("car_maxls1", CAR, dict(CAR_SP, max_ls=1), X0[:8], rng.standard_normal((8, 39, 2)) * 0.5, pool)
+    run_cases("car_maxls2", CAR, dict(CAR_SP, max_ls=2), X0[:8], rng.standard_normal((8, 39, 2)) * 2.0, pool)
+    # max_iter exhaustion
+    run_cases("car_maxiter2", CAR, dict(CAR_SP, max_iter=2), X0[:8], rng.standard_normal((8, 39, 2)) * 1e-4, pool)
+    # loose d_tol so the loop ends through the d_tol test
+    run_cases("car_dtol", CAR, dict(CAR_SP, d_tol=50.0), X0[:16], rng.standard_normal((16, 39, 2)) * 1e-4, pool)
+    # huge controls: overflow -> inf/NaN initial rollout -> LinAlgError in eigvals
+    u = rng.standard_normal((4, 39, 2)) * 1e155
+    run_cases("car_nan", CAR, CAR_SP, X0[:4], u, pool, check_stable=False)
+    # short and long horizons
+    run_cases("car_N2", CAR, dict(CAR_SP, N=2), X0[:8], rng.standard_normal((8, 1, 2)) * 0.1, pool)
+    run_cases("car_N200", CAR, dict(CAR_SP, N=200), X0[:8], rng.standard_normal((8, 199, 2)) * 1e-4, pool)
+
+
+def gen_acrobot(pool):
+    rng = np.random.default_rng(2)
+    B = 32
+    sp = dict(N=100, max_iter=20, max_ls=10, d_tol=1e-3)
+    X0 = np.column_stack([rng.uniform(-np.pi, np.pi, B), rng.uniform(-np.pi, np.pi, B),
+                          rng.uniform(-1, 1, B), rng.uniform(-1, 1, B)])
+    run_cases("acrobot_N100", acrobot_spec(100), sp, X0, rng.standard_normal((B, 99, 1)), pool)
+    run_cases("acrobot_N40", acrobot_spec(40), dict(sp, N=40), X0[:16], rng.standard_normal((16, 39, 1)), pool)
+
+
+def gen_quad_ea(pool):
+    rng = np.random.default_rng(3)
+    B = 16
+    sp = dict(N=100, max_iter=20, max_ls=10, d_tol=5e-4)
+    X0 = np.zeros((B, 12)); X0[:, 2] = 0.8; X0[:, 3:6] = 0.5 * rng.standard_normal((B, 3))
+    run_cases("quad_ea_N100", ea_spec(100), sp, X0, 2.0 * rng.standard_normal((B, 99, 4)), pool)
+    run_cases("quad_ea_N30", ea_spec(30), dict(sp, N=30), X0, 2.0 * rng.standard_normal((B, 29, 4)), pool)
+
+
+def gen_quad_quat(pool):
+    rng = np.random.default_rng(4)
+    B = 16
+    sp = dict(N=80, max_iter=20, max_ls=10, d_tol=5e-4)
+    X0 = np.zeros((B, 13)); X0[:, 6] = 0.8
+    for b in range(B):
+        X0[b, :4] = euler_zyx_to_quat(0.5 * rng.standard_normal(3))
+    run_cases("quad_quat_N80", quat_spec(80), sp, X0, 2.0 * rng.standard_normal((B, 79, 4)), pool)
+    run_cases("quad_quat_N30", quat_spec(30), dict(sp, N=30), X0, 2.0 * rng.standard_normal((B, 29, 4)), pool)
+    # receding horizon (QuadrotorControllers.py:173-191): solve, step the plant with u[0], shift u, re-solve
+    spec = quat_spec(30)
+    spm = dict(sp, N=30)
+    plant = make_plant(spec)
+    X0s, U0s = [], []
+    for b in range(2):
+        x0 = X0[b].copy(); u = 2.0 * rng.standard_normal((29, 4))
+        for step in range(6):
+            X0s.append(x0.copy()); U0s.append(u.copy())
+            r = run_reference(plant, spm, x0, u)
+            u = r["u"]
+            x0 = np.asarray(plant.discrete_dynamics(x0, u[0])).ravel()
+            u[:-1] = u[1:]
+    run_cases("quad_quat_mpc", spec, spm, np.array(X0s), np.array(U0s), pool,
+              extra=dict(mpc_steps=6, mpc_traj=2))
+
+
+def gen_units(pool):
+    """Pure functions of the reference solver on random blocks (iLQRController.py:125-147, model.py:45-53)."""
+    from control.iLQRController import iLQR
+    from control.models.model import Model
+    rng = np.random.default_rng(99)
+
+    class Dummy(Model):
+        def __init__(self, n, m):
+            self.nx, self.nu, self.ndx = n, m, n
+
+    out = {}
+    for tag, (n, m) in dict(car=(5, 2), acrobot=(4, 1), quad=(12, 4)).items():
+        ctl = iLQR(Dummy(n, m), 10, 1)
+        T = 16
+        keys = ["lx", "lu", "lxx", "lux", "luu", "fx", "fu", "Vx", "Vxx", "Qx", "Qu", "Qxx", "Qux", "Quu",
+                "d", "K", "Vx2", "Vxx2", "ecr", "fullH"]
+        acc = {k: [] for k in keys}
+        for _ in range(T):
+            A = rng.standard_normal((n, n)); lxx = A @ A.T
+            Bm = rng.standard_normal((m, m)); luu = Bm @ Bm.T + np.eye(m)
+            Cm = rng.standard_normal((n, n)); Vxx = Cm @ Cm.T
+            lx, lu, Vx = rng.standard_normal(n), rng.standard_normal(m), rng.standard_normal(n)
+            lux = rng.standard_normal((m, n)); fx = np.eye(n) + 0.1 * rng.standard_normal((n, n))
+            fu = rng.standard_normal((n, m))
+            Qx, Qu, Qxx, Qux, Quu = ctl.model.Q_terms(None, lx, lu, lxx, lux, luu, fx, fu, Vx, Vxx)
+            d, K = ctl._gains(Quu, Qu, Qux)
+            Vx2, Vxx2 = ctl._V_terms(Qx, Qu, Qxx, Qux, Quu, K, d)
+            ecr = ctl._expected_cost_reduction(Qu, Quu, d)
+            fullH = ctl._full_hessian(Qxx, Qux, Quu)
+            for k, v in zip(keys, [lx, lu, lxx, lux, luu, fx, fu, Vx, Vxx, Qx, Qu, Qxx, Qux, Quu, d, K, Vx2, Vxx2,
+                                   ecr, fullH]):
+                acc[k].append(np.asarray(v, dtype=np.float64))
+        for k in keys:
+            out[f"{tag}_{k}"] = np.stack(acc[k])
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "units.npz"), **out)
+    print("[golden] units", flush=True)
+
+
+GENS = dict(car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
+            acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat, units=gen_units)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--jobs", type=int, default=8)
+    a = ap.parse_args()
+    which = [w for w in a.only.split(",") if w] or list(GENS)
+    with ProcessPoolExecutor(max_workers=a.jobs) as pool:
+        for w in which:
+            GENS[w](pool)
+
+
+if __name__ == "__main__":
+    main()
