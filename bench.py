@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched CarModel N=40 iLQR solves per second on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+One step = one pass of the hot path (ilqr_solve_batch) over one batch of B synthetic
+problems per GPU whose inputs are already resident in HBM in the library's strided
+structure-of-arrays layout.  Workload (per GPU, weak scaling): CarModel(r=2, v_target=2),
+N=40, max_iter=50, max_linesearch_iters=20, d_tol=1e-3; x0 ~ U([-4,4]^2) x U(-pi,pi) x
+U(0,3) x U(-0.3,0.3), u_init ~ N(0, 1e-4^2), default_rng(1234 + rank); B = 2^20.
+
+For N > 1 the driver starts one process per GPU (torch.distributed.run); every rank solves
+its own shard with no data-path collective, then the per-trajectory costs / iteration
+counts / exit codes are all-gathered over RCCL, which is the path's only exchange.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline:     algorithmic fp64 flops of the solves (dense formulas, actual per-trajectory
+                iteration / regularisation / line-search counts) / kernel time vs the fp64
+                vector peak, plus the same for algorithmic bytes vs HBM peak;
+  cpu_baseline: the CPU checker (oracle/, a C restatement of the reference solver) on a
+                bounded sample of the same batch, one OpenMP thread per host core.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: half the 157.3 TFLOP/s fp32 vector peak (non-MFMA)
+HBM_PEAK_GBS = 8000.0
+
+
+def car_inputs(B, seed):
+    rng = np.random.default_rng(seed)
+    x0 = np.column_stack([rng.uniform(-4, 4, B), rng.uniform(-4, 4, B), rng.uniform(-np.pi, np.pi, B),
+                          rng.uniform(0, 3, B), rng.uniform(-0.3, 0.3, B)])
+    u0 = rng.standard_normal((B, 39, 2)) * 1e-4
+    return x0, u0
+
+
+def algorithmic_flops(n, m, S, ops, iters, regu_rounds, regu_stages, ls_total, B):
+    """Dense flop count of the solves actually performed (FMA = 2, sin/cos/tan/sqrt/div = 1, no
+    sparsity or symmetry credit); sums over the batch are passed in."""
+    F_dyn, F_cost, F_costf = ops["dyn"]["flops"], ops["cost_stage"]["flops"], ops["cost_final"]["flops"]
+    F_deriv = ops["stage"]["flops"]
+    base = (4 * n**3 + 8 * n * n * m + 6 * n * m * m + m**3 / 3 + (n + m) ** 3 / 3 + 6 * n * n + 9 * n * m + 5 * m * m
+            + 4 * n + 5 * m + 2 + F_deriv)
+    per_round = (n + m) ** 3 / 3 + 2 * (n * n + n * m + m * m)
+    per_regu_stage = 2 * n**3 + 2 * n * n * m + 2 * n * m * m
+    F_fwd = n + 2 * m * n + 3 * m + F_dyn + F_cost
+    total = B * (S * (F_dyn + F_cost) + F_costf)
+    total += iters * (S * base + ops["final"]["flops"]) + regu_rounds * per_round + regu_stages * per_regu_stage
+    total += ls_total * (S * F_fwd + F_costf)
+    return float(total)
+
+
+def algorithmic_bytes(nx, m, N, B):
+    S = N - 1
+    return float(B * (8 * (nx + S * m) + 8 * (N * nx + S * m + 1) + 12))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="trajectories per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="trajectories timed on the host cores (0 = skip)")
+    ap.add_argument("--check", type=int, default=2048, help="trajectories checked against the CPU checker (0 = skip)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+    dev = torch.device("cuda", local)
+
+    from ilqr_amd.batch import BatchSolver
+    B, N, nx, m, n = a.batch, 40, 5, 2, 5
+    S = N - 1
+    solver = BatchSolver(0, [2.0, 2.0], N, 50, 20, 1e-3, device=dev)
+    x0_np, u0_np = car_inputs(B, 1234 + rank)
+    x0 = torch.as_tensor(x0_np).to(dev).t().contiguous()                  # [nx, B]
+    u_init = torch.as_tensor(u0_np).to(dev).permute(1, 2, 0).contiguous()  # [S, m, B]
+    u = torch.empty_like(u_init)
+    x = torch.empty((N, nx, B), dtype=torch.float64, device=dev)
+    out = solver.alloc_outputs(B)
+    gathered = None
+    if dist is not None:
+        gathered = {k: torch.empty(world * B, dtype=out[k].dtype, device=dev) for k in ("J", "iters", "status")}
+
+    def step(ev=None):
+        u.copy_(u_init)                       # run_ilqr optimises u in place: restore the initial guess
+        if ev:
+            ev[0].record()
+        solver.solve_soa(x0, u, x, out)
+        if ev:
+            ev[1].record()
+        if dist is not None:
+            for k, g in gathered.items():
+                dist.all_gather_into_tensor(g, out[k])
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(evs[k])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+
+    # counts of the work actually done (rank 0's shard; every shard is statistically alike)
+    iters = int(out["iters"].sum().item())
+    regu_rounds = int(out["regu_rounds"].sum().item())
+    regu_stages = int(out["regu_stages"].sum().item())
+    ls_total = int(out["ls_total"].sum().item())
+    status = torch.bincount(out["status"], minlength=4).cpu().tolist()
+
+    if rank == 0:
+        ops = json.load(open(os.path.join(ROOT, "ilqr_amd", "csrc", "gen", "opcounts.json")))["car"]
+        flops = algorithmic_flops(n, m, S, ops, iters, regu_rounds, regu_stages, ls_total, B)
+        byts = algorithmic_bytes(nx, m, N, B)
+        tfl = flops / (kernel_ms * 1e-3) / 1e12
+        gbs = byts / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        value = world * B * a.steps / elapsed
+        res = {
+            "metric": "iLQR solves/sec (CarModel N=40, batched)", "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "CarModel(r=2,v_target=2) N=40 max_iter=50 max_ls=20 d_tol=1e-3, x0 uniform box, "
+                                   "u_init N(0,1e-8), seed 1234+rank", "batch_per_gpu": B, "global_batch": world * B,
+                       "layout": "strided SoA resident in HBM", "parallelism": f"shard{world}"},
+            "ms_per_iter": 1e3 * elapsed / a.steps / max(iters / B, 1e-9),
+            "mean_iters": iters / B, "mean_ls_evals": ls_total / B, "mean_regu_rounds": regu_rounds / B,
+            "exit_counts": {"d_tol": status[0], "deltaJ<1": status[1], "max_iter": status[2], "linalg": status[3]},
+            "roofline": {"bound": "valu_fp64", "achieved": tfl, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tfl / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
+                         "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": byts}},
+        }
+        # ---- parity spot check and CPU baseline (rank 0, N=1 only for the baseline) ----
+        if a.check or (a.cpu_sample and world == 1):
+            from oracle import c_oracle as co
+            co.build()
+            cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+            par = co.pack_car(2.0, 2.0)
+            if a.check:
+                c = min(a.check, B)
+                ref = co.solve_batch("car", par, N, 50, 20, 1e-3, x0_np[:c], u0_np[:c], nthreads=cores)
+                it = out["iters"][:c].cpu().numpy()
+                same = it == ref["info"]["iters"]
+                calm = ref["info"]["max_abs_q"] < 1e5
+                xg = x[:, :, :c].permute(2, 0, 1).cpu().numpy()
+                err = np.abs(xg - ref["x"]).reshape(c, -1).max(1) / np.abs(ref["x"]).reshape(c, -1).max(1)
+                res["parity_check"] = {"checked": int(c), "iters_identical": int(same.sum()),
+                                       "well_conditioned": int(calm.sum()),
+                                       "well_conditioned_iters_identical": int((same & calm).sum()),
+                                       "max_rel_x_err_well_conditioned": float(err[same & calm].max())}
+            if a.cpu_sample and world == 1:
+                c = min(a.cpu_sample, B)
+                t1 = time.perf_counter()
+                co.solve_batch("car", par, N, 50, 20, 1e-3, x0_np[:c], u0_np[:c], nthreads=cores)
+                dt = time.perf_counter() - t1
+                res["cpu_baseline"] = {"value": c / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+                                       "sample": f"first {c} trajectories of the same batch, C restatement of the "
+                                                 f"reference solver (oracle/), OpenMP over {cores} threads, {dt:.1f} s"}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

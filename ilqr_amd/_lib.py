@@ -31,7 +31,7 @@ class Problem(C.Structure):
 
 class Outputs(C.Structure):
     _fields_ = [(k, _dp) for k in ("J0", "J", "dmax", "max_abs_q", "iters", "status", "regu_rounds", "ls_total",
-                                   "ls_evals", "accepted", "J_trace", "deltaJ_trace")]
+                                   "regu_stages", "ls_evals", "accepted", "J_trace", "deltaJ_trace")]
 
 
 class LibraryMissing(RuntimeError):

@@ -41,6 +41,7 @@ class BatchResult:
     status: torch.Tensor
     regu_rounds: torch.Tensor
     ls_total: torch.Tensor
+    regu_stages: torch.Tensor = None
     traces: dict = field(default_factory=dict)
 
 
@@ -94,7 +95,8 @@ class BatchSolver:
                  iters=torch.empty(stride, dtype=torch.int32, device=dev),
                  status=torch.empty(stride, dtype=torch.int32, device=dev),
                  regu_rounds=torch.empty(stride, dtype=torch.int32, device=dev),
-                 ls_total=torch.empty(stride, dtype=torch.int32, device=dev))
+                 ls_total=torch.empty(stride, dtype=torch.int32, device=dev),
+                 regu_stages=torch.empty(stride, dtype=torch.int32, device=dev))
         if self.trace_len:
             T = self.trace_len
             o.update(ls_evals=torch.zeros((T, stride), dtype=torch.int32, device=dev),
@@ -143,7 +145,7 @@ class BatchSolver:
         return BatchResult(x=xs.permute(2, 0, 1).contiguous(), u=us.permute(2, 0, 1).contiguous(),
                            J0=out["J0"], J=out["J"], dmax=out["dmax"], max_abs_q=out["max_abs_q"],
                            iters=out["iters"], status=out["status"], regu_rounds=out["regu_rounds"],
-                           ls_total=out["ls_total"], traces=tr)
+                           ls_total=out["ls_total"], regu_stages=out["regu_stages"], traces=tr)
 
     def rollout_cost(self, x0, u):
         """Model.rollout + cost_trj for a batch: returns (x [B, N, nx], J [B])."""

@@ -1,15 +1,14 @@
 // libilqr_hip: kernels and C ABI (see include/ilqr_hip.h).
 //
-// Launch shape: one lane per trajectory, 64-lane workgroups (one wavefront),
-// so a trajectory's whole solve runs in one lane and the 64 trajectories of a
-// wavefront advance in lockstep; data-dependent trip counts (regularisation
-// rounds, backtracking steps, iterations) are handled by predication.
+// Launch shape: one lane per trajectory, 64-lane workgroups (one wavefront).
+// The batched solve is a pipeline of per-iteration kernels (solve_pipeline.hpp).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
 
 #include "../../include/ilqr_hip.h"
 #include "solver_device.hpp"
+#include "solve_pipeline.hpp"
 
 using namespace ilqr;
 
@@ -36,75 +35,6 @@ struct Dev {
 constexpr int WG = 64;
 
 // ---------------------------------------------------------------- kernels
-template <class M>
-__global__ __launch_bounds__(WG) void solve_kernel(Dev a, const double* __restrict__ x0, double* __restrict__ u,
-                                                   double* __restrict__ x, double* __restrict__ wsD,
-                                                   double* __restrict__ wsK, double* __restrict__ wsXn,
-                                                   double* __restrict__ wsUn)
-{
-    constexpr int n = M::NDX, m = M::NU, nx = M::NX;
-    const long b = (long)blockIdx.x * WG + threadIdx.x;
-    if (b >= a.p.B) return;
-    const long st = a.p.stride;
-    const int N = a.p.N, S = N - 1;
-    const double* par = a.p.params;
-    const Lane X{x + b, st}, U{u + b, st}, D{wsD + b, st}, K{wsK + b, st}, Xn{wsXn + b, st}, Un{wsUn + b, st};
-    const CLane cX{x + b, st}, cU{u + b, st}, cD{wsD + b, st}, cK{wsK + b, st}, cXn{wsXn + b, st}, cUn{wsUn + b, st};
-
-    double xs[nx];
-    for (int i = 0; i < nx; ++i) xs[i] = x0[(long)i * st + b];
-    double J = rollout_cost<M>(par, xs, cU, X, S);           // iLQRController.py:27-34
-    const double J0 = J;
-
-    int iters = 0, status = ILQR_EXIT_DTOL, regu_rounds = 0, ls_total = 0;
-    double dmax = INFINITY, maxq = 0.0;                      // d = DBL_MAX -> norm overflows to +inf (:37, :43)
-    const int max_iter = a.p.max_iter, max_ls = a.p.max_ls, T = a.p.trace_len;
-    const double d_tol = a.p.d_tol;
-    for (;;) {
-        if (!(dmax > d_tol)) { status = ILQR_EXIT_DTOL; break; }
-        if (!(iters < max_iter)) { status = ILQR_EXIT_MAXITER; break; }
-        iters += 1;
-        double deltaJ = 0.0;
-        if (!backward_pass<M>(par, cX, cU, D, K, S, deltaJ, dmax, regu_rounds, maxq)) {
-            status = ILQR_EXIT_LINALG;
-            break;
-        }
-        if (iters <= T && a.o.deltaJ_trace) a.o.deltaJ_trace[(long)(iters - 1) * st + b] = deltaJ;
-        if (deltaJ < 1.0) { status = ILQR_EXIT_SMALL_DELTAJ; break; }     // :50-51
-        int ls = 0;
-        bool complete = false, abandon = false;
-        double alpha = 1.0, Jn = 0.0;
-        while (!complete && !abandon) {                                   // :60-68
-            ls += 1;
-            Jn = forward_pass<M>(par, cX, cU, cD, cK, alpha, Xn, Un, S);
-            complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < max_ls);
-            abandon = (Jn != Jn) || (ls >= max_ls);
-            alpha *= 0.5;
-        }
-        if (complete) {                                                   // :69-72
-            for (int i = 0; i < N * nx; ++i) X.st(i, cXn.ld(i));
-            for (int i = 0; i < S * m; ++i) U.st(i, cUn.ld(i));
-        }
-        if (iters <= T) {
-            const long q = (long)(iters - 1) * st + b;
-            if (a.o.ls_evals) a.o.ls_evals[q] = ls;
-            if (a.o.accepted) a.o.accepted[q] = complete ? 1 : 0;
-            if (a.o.J_trace) a.o.J_trace[q] = Jn;
-        }
-        ls_total += ls;
-        J = Jn;                                                           // :79
-    }
-    if (a.o.J0) a.o.J0[b] = J0;
-    if (a.o.J) a.o.J[b] = J;
-    if (a.o.dmax) a.o.dmax[b] = dmax;
-    if (a.o.max_abs_q) a.o.max_abs_q[b] = maxq;
-    if (a.o.iters) a.o.iters[b] = iters;
-    if (a.o.status) a.o.status[b] = status;
-    if (a.o.regu_rounds) a.o.regu_rounds[b] = regu_rounds;
-    if (a.o.ls_total) a.o.ls_total[b] = ls_total;
-    (void)n;
-}
-
 template <class M>
 __global__ __launch_bounds__(WG) void rollout_kernel(Dev a, const double* __restrict__ x0,
                                                      const double* __restrict__ u, double* __restrict__ x,
@@ -209,20 +139,107 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
 }
 
 struct WsLayout {
-    size_t d, k, xn, un, total;
+    size_t XA, XB, UA, UB, D, K, dJ, J0, J, dmax, maxq, iters, status, regu_rounds, regu_stages, ls_total, idA, idB,
+        ls_slot, ls_dest, bt, cnt, total;
 };
 WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
 {
-    const size_t st = (size_t)p->stride, S = (size_t)p->N - 1;
-    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    WsLayout w;
+    const size_t cap = (size_t)p->stride, S = (size_t)p->N - 1, N = (size_t)p->N;
     size_t off = 0;
-    w.d = off; off += al(S * d.nu * st * 8);
-    w.k = off; off += al(S * d.nu * d.ndx * st * 8);
-    w.xn = off; off += al((S + 1) * d.nx * st * 8);
-    w.un = off; off += al(S * d.nu * st * 8);
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    WsLayout w;
+    w.XA = take(N * d.nx * cap * 8); w.XB = take(N * d.nx * cap * 8);
+    w.UA = take(S * d.nu * cap * 8); w.UB = take(S * d.nu * cap * 8);
+    w.D = take(S * d.nu * cap * 8);  w.K = take(S * d.nu * d.ndx * cap * 8);
+    w.dJ = take(cap * 8);
+    w.J0 = take(cap * 8); w.J = take(cap * 8); w.dmax = take(cap * 8); w.maxq = take(cap * 8);
+    w.iters = take(cap * 4); w.status = take(cap * 4); w.regu_rounds = take(cap * 4); w.regu_stages = take(cap * 4);
+    w.ls_total = take(cap * 4);
+    w.idA = take(cap * 4); w.idB = take(cap * 4); w.ls_slot = take(cap * 4); w.ls_dest = take(cap * 4);
+    w.bt = take(cap * 4);
+    w.cnt = take(64);
     w.total = off;
     return w;
+}
+
+inline unsigned blocks_for(long n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// run_ilqr for the whole batch: see solve_pipeline.hpp.  Blocks the calling thread on `stream`
+// twice per solver iteration to size the next launch (a 12-byte read-back).
+template <class M>
+int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, const ilqr_outputs* out, char* ws,
+                 const WsLayout& w, hipStream_t st)
+{
+    Pipe a;
+    memset(&a, 0, sizeof(a));
+    a.N = p->N; a.max_iter = p->max_iter; a.max_ls = p->max_ls; a.trace_len = p->trace_len; a.flags = p->flags;
+    a.d_tol = p->d_tol; a.B = p->B; a.cap = p->stride; a.par = p->params;
+    a.x0 = x0; a.u = u; a.x = x;
+    ilqr_outputs o;
+    if (out) o = *out; else memset(&o, 0, sizeof(o));
+    a.J0 = o.J0 ? o.J0 : (double*)(ws + w.J0);
+    a.J = o.J ? o.J : (double*)(ws + w.J);
+    a.dmax = o.dmax ? o.dmax : (double*)(ws + w.dmax);
+    a.maxq = o.max_abs_q ? o.max_abs_q : (double*)(ws + w.maxq);
+    a.iters = o.iters ? o.iters : (int32_t*)(ws + w.iters);
+    a.status = o.status ? o.status : (int32_t*)(ws + w.status);
+    a.regu_rounds = o.regu_rounds ? o.regu_rounds : (int32_t*)(ws + w.regu_rounds);
+    a.regu_stages = o.regu_stages ? o.regu_stages : (int32_t*)(ws + w.regu_stages);
+    a.ls_total = o.ls_total ? o.ls_total : (int32_t*)(ws + w.ls_total);
+    a.tr_ls = o.ls_evals; a.tr_acc = o.accepted; a.tr_J = o.J_trace; a.tr_dJ = o.deltaJ_trace;
+    a.XA = (double*)(ws + w.XA); a.XB = (double*)(ws + w.XB); a.UA = (double*)(ws + w.UA); a.UB = (double*)(ws + w.UB);
+    a.D = (double*)(ws + w.D); a.K = (double*)(ws + w.K); a.dJ = (double*)(ws + w.dJ);
+    a.idA = (int32_t*)(ws + w.idA); a.idB = (int32_t*)(ws + w.idB);
+    a.ls_slot = (int32_t*)(ws + w.ls_slot); a.ls_dest = (int32_t*)(ws + w.ls_dest); a.bt = (int32_t*)(ws + w.bt);
+    a.cnt = (int32_t*)(ws + w.cnt);
+
+    hipLaunchKernelGGL(pipe_init_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    // the loop test of iLQRController.py:43 before the first iteration: max|d| is +inf there
+    if (!(INFINITY > a.d_tol) || !(0 < a.max_iter)) {
+        const int status = !(INFINITY > a.d_tol) ? ILQR_EXIT_DTOL : ILQR_EXIT_MAXITER;
+        hipLaunchKernelGGL(pipe_finish_all_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a, status);
+        HIP_TRY(hipGetLastError());
+        return ILQR_OK;
+    }
+    const bool parallel_ls = (a.flags & ILQR_FLAG_PARALLEL_LS) && a.max_ls >= 2 && a.max_ls - 1 <= 64;
+    int32_t h[3];
+    long count = a.B;
+    for (int iter = 1; iter <= a.max_iter && count > 0; ++iter) {
+        a.count = (int)count;
+        a.iter = iter;
+        HIP_TRY(hipMemsetAsync(a.cnt, 0, 3 * sizeof(int32_t), st));
+        hipLaunchKernelGGL(pipe_backward_kernel<M>, dim3(blocks_for(count, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h, a.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const long next = h[0], nls = h[1];
+        if (nls > 0) {
+            hipLaunchKernelGGL(pipe_forward1_kernel<M>, dim3(blocks_for(nls, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h + 2, a.cnt + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const long nbt = h[2];
+            if (nbt > 0) {
+                if (parallel_ls) {
+                    const int per_wave = 64 / (a.max_ls - 1);
+                    hipLaunchKernelGGL(pipe_backtrack_parallel_kernel<M>, dim3(blocks_for(nbt, per_wave)),
+                                       dim3(PIPE_WG), 0, st, a);
+                } else {
+                    hipLaunchKernelGGL(pipe_backtrack_kernel<M>, dim3(blocks_for(nbt, PIPE_WG)), dim3(PIPE_WG), 0, st,
+                                       a);
+                }
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        // the buffer the candidates were written to becomes the current one
+        double* t;
+        t = a.XA; a.XA = a.XB; a.XB = t;
+        t = a.UA; a.UA = a.UB; a.UB = t;
+        int32_t* ti = a.idA; a.idA = a.idB; a.idB = ti;
+        count = next;
+    }
+    return ILQR_OK;
 }
 
 template <class F>
@@ -269,20 +286,13 @@ int ilqr_solve_batch(const ilqr_problem* p, const double* x0, double* u, double*
     int rc = check_problem(p, d);
     if (rc) return rc;
     if (!x0 || !u || !x) return fail(ILQR_E_BADARG, "x0, u and x must be non-NULL");
+    if (p->stride > 0x7fffffffL) return fail(ILQR_E_BADARG, "stride must fit in 31 bits");
     WsLayout w = ws_layout(p, d);
     if (!workspace || workspace_bytes < w.total) return fail(ILQR_E_WORKSPACE, "workspace missing or too small");
-    Dev a;
-    a.p = *p;
-    if (out) a.o = *out; else memset(&a.o, 0, sizeof(a.o));
-    char* ws = (char*)workspace;
-    dim3 grid((unsigned)((p->B + WG - 1) / WG)), block(WG);
     hipStream_t s = (hipStream_t)stream;
     return dispatch(p->model_id, [&](auto M) {
         using Mt = decltype(M);
-        hipLaunchKernelGGL(solve_kernel<Mt>, grid, block, 0, s, a, x0, u, x, (double*)(ws + w.d), (double*)(ws + w.k),
-                           (double*)(ws + w.xn), (double*)(ws + w.un));
-        HIP_TRY(hipGetLastError());
-        return (int)ILQR_OK;
+        return run_pipeline<Mt>(p, x0, u, x, out, (char*)workspace, w, s);
     });
 }
 

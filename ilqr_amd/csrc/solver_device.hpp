@@ -168,21 +168,67 @@ __device__ inline bool inv_small(const double* A, double* Ainv)
 }
 
 // ------------------------------------------------------------------
+// Regularisation loop of iLQRController.py:106-115,
+//     regu = 0.1; while any(eigvals(Q) < 0): Q += (regu [fx fu])'[fx fu]; regu *= 2
+// Because regu is 0.1 times a power of two, the update of round r is exactly
+// 2^r * P with P = (0.1 [fx fu])'[fx fu] evaluated once in the reference's
+// operation order, so "after r rounds" is a matrix Q(r) every lane can build:
+//   r <= REGU_EXACT : Q(r) = Q(r-1) + 2^(r-1) P, accumulated one by one as the reference does;
+//   r >  REGU_EXACT : Q(r) = Q(REGU_EXACT) + (2^r - 2^REGU_EXACT) P, the same sum up to rounding
+//                     (only ill-conditioned solves need more than ~8 rounds).
+// The result of the loop is the first r = 0, 1, 2, ... whose Q(r) has no negative eigenvalue.
+//
+// Execution: the first REGU_LOCKSTEP rounds run lane by lane.  A lane that
+// still fails then is "stuck" (typically ~50 rounds until regu swamps the
+// curvature); instead of making the other 63 trajectories of the wavefront
+// wait through its scan, the wavefront scans for it: the stuck lane publishes
+// Q(REGU_LOCKSTEP) and P in LDS, lane l tests Q(REGU_LOCKSTEP + 1 + l), a ballot
+// picks the first r that stops the scan, and that lane hands Q(r) back.
+// ------------------------------------------------------------------
+constexpr int REGU_LOCKSTEP = 4;
+constexpr int REGU_EXACT = 12;
+
+template <int n, int m>
+struct QPack {
+    static constexpr int NQ = n * n + m * n + m * m;
+    static constexpr int LDS_DOUBLES = 2 * NQ + 4;      // per-wavefront record: Q, P, then {test result, r, max|Q|}
+};
+
+// Q(r) for one entry, from q = Q(REGU_LOCKSTEP) and p = P
+__device__ __forceinline__ double regu_entry(double q, double p, int r, double coef)
+{
+    double pw = (double)(1 << REGU_LOCKSTEP);
+#pragma unroll
+    for (int i = REGU_LOCKSTEP; i < REGU_EXACT; ++i) {
+        q = (i < r) ? q + pw * p : q;        // pw * p is exact (power of two), so contraction cannot change it
+        pw *= 2.0;
+    }
+    return (r > REGU_EXACT) ? __dadd_rn(q, __dmul_rn(coef, p)) : q;
+}
+
+// ------------------------------------------------------------------
 // One stage of the backward Riccati sweep: iLQRController.py:103-122 with
 // Model.Q_terms (model.py:45-53), the regularisation loop (:106-115), _gains
 // (:125-129), _V_terms (:131-134) and _expected_cost_reduction (:136-137).
 // Vx/Vxx are updated in place; d_k and K_k are returned in dk/Kk.
+// Must be called by all 64 lanes of the wavefront together (`alive` = this
+// lane carries a trajectory); `lds` is the wavefront's QPack record.
 // Returns false on the LinAlgError cases.
 // ------------------------------------------------------------------
 template <class M>
 __device__ inline bool backward_stage(const double* par, const double* xk, const double* uk, double* Vx, double* Vxx,
-                                      double* dk, double* Kk, double& redu, int& regu_rounds, double& maxq)
+                                      double* dk, double* Kk, double& redu, int& regu_rounds, int& regu_stages,
+                                      double& maxq, bool alive, double* lds)
 {
     constexpr int n = M::NDX, m = M::NU;
+    constexpr int NQ = QPack<n, m>::NQ;
     double lx[n], lu[m], lxx[n * n], lux[m * n], luu[m * m], fx[n * n], fu[n * m];
     M::stage(par, xk, uk, lx, lu, lxx, lux, luu, fx, fu);
 
-    double Qx[n], Qu[m], Qxx[n * n], Qux[m * n], Quu[m * m];
+    double Qx[n], Qu[m], QQ[NQ];
+    double* const Qxx = QQ;
+    double* const Qux = QQ + n * n;
+    double* const Quu = QQ + n * n + m * n;
     {
         // Q_x = l_x + f_x' V_x ; Q_u = l_u + f_u' V_x
         for (int i = 0; i < n; ++i) {
@@ -230,33 +276,94 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
         }
     }
 
-    // regularisation: while any(eigvals(Q) < 0): Q += regu [fx fu]'[fx fu]; regu *= 2
-    double regu = 0.1;
-    for (;;) {
-        int neg = has_negative_eig<n, m>(Qxx, Qux, Quu, maxq);
-        if (neg < 0) return false;
-        if (neg == 0) break;
+    // ---- regularisation, rounds 0..REGU_LOCKSTEP lane by lane
+    bool ok = true;
+    int r = 0;
+    int neg = has_negative_eig<n, m>(Qxx, Qux, Quu, maxq);
+    ok = ok && (neg >= 0);
+    bool need = alive && (neg == 1);
+    double PP[NQ];
+    if (need) {
+        regu_stages += 1;
+        double* const Pxx = PP;
+        double* const Pux = PP + n * n;
+        double* const Puu = PP + n * n + m * n;
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) {
                 double s = 0.0;
-                for (int t = 0; t < n; ++t) s += (regu * fx[t * n + i]) * fx[t * n + j];
-                Qxx[i * n + j] += s;
+                for (int t = 0; t < n; ++t) s += (0.1 * fx[t * n + i]) * fx[t * n + j];
+                Pxx[i * n + j] = s;
             }
         for (int i = 0; i < m; ++i) {
             for (int j = 0; j < m; ++j) {
                 double s = 0.0;
-                for (int t = 0; t < n; ++t) s += (regu * fu[t * m + i]) * fu[t * m + j];
-                Quu[i * m + j] += s;
+                for (int t = 0; t < n; ++t) s += (0.1 * fu[t * m + i]) * fu[t * m + j];
+                Puu[i * m + j] = s;
             }
             for (int j = 0; j < n; ++j) {
                 double s = 0.0;
-                for (int t = 0; t < n; ++t) s += (regu * fu[t * m + i]) * fx[t * n + j];
-                Qux[i * n + j] += s;
+                for (int t = 0; t < n; ++t) s += (0.1 * fu[t * m + i]) * fx[t * n + j];
+                Pux[i * n + j] = s;
             }
         }
-        regu *= 2.0;
-        regu_rounds += 1;
     }
+    double pw = 1.0;
+    while (need && r < REGU_LOCKSTEP) {
+        for (int e = 0; e < NQ; ++e) QQ[e] += pw * PP[e];
+        pw *= 2.0;
+        r += 1;
+        neg = has_negative_eig<n, m>(Qxx, Qux, Quu, maxq);
+        ok = ok && (neg >= 0);
+        need = (neg == 1);
+    }
+
+    // ---- lanes still failing: the wavefront scans r = REGU_LOCKSTEP+1, +2, ... for them, 64 at a time
+    unsigned long long stuck = __ballot(need);
+    const int lane = threadIdx.x & 63;
+    while (stuck) {
+        const int src = __ffsll((long long)stuck) - 1;
+        stuck &= stuck - 1;
+        __syncthreads();
+        if (lane == src)
+            for (int e = 0; e < NQ; ++e) {
+                lds[e] = QQ[e];
+                lds[NQ + e] = PP[e];
+            }
+        __syncthreads();
+        for (int base = REGU_LOCKSTEP + 1;; base += 64) {
+            const int rc = base + lane;
+            const double coef = ldexp(1.0, rc) - ldexp(1.0, REGU_EXACT);
+            double W[NQ];
+            for (int e = 0; e < NQ; ++e) W[e] = regu_entry(lds[e], lds[NQ + e], rc, coef);
+            double mq = 0.0;
+            const int t = has_negative_eig<n, m>(W, W + n * n, W + n * n + m * n, mq);
+            const unsigned long long stops = __ballot(t != 1);
+            if (stops) {
+                const int win = __ffsll((long long)stops) - 1;
+                __syncthreads();
+                if (lane == win) {
+                    for (int e = 0; e < NQ; ++e) lds[e] = regu_entry(lds[e], lds[NQ + e], rc, coef);
+                    lds[2 * NQ] = (double)t;
+                    lds[2 * NQ + 1] = (double)rc;
+                    lds[2 * NQ + 2] = mq;
+                }
+                __syncthreads();
+                if (lane == src) {
+                    for (int e = 0; e < NQ; ++e) QQ[e] = lds[e];
+                    ok = ok && (lds[2 * NQ] >= 0.0);
+                    r = (int)lds[2 * NQ + 1];
+                    maxq = (lds[2 * NQ + 2] > maxq) ? lds[2 * NQ + 2] : maxq;
+                }
+                break;
+            }
+            if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
+                if (lane == src) ok = false;
+                break;
+            }
+        }
+    }
+    regu_rounds += r;
+    if (!ok) return false;
 
     // gains: d = -Quu^-1 Qu, K = -Quu^-1 Qux
     double Qinv[m * m];
@@ -266,9 +373,9 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
         for (int t = 0; t < m; ++t) s += (-Qinv[i * m + t]) * Qu[t];
         dk[i] = s;
         for (int j = 0; j < n; ++j) {
-            double r = 0.0;
-            for (int t = 0; t < m; ++t) r += (-Qinv[i * m + t]) * Qux[t * n + j];
-            Kk[i * n + j] = r;
+            double rr = 0.0;
+            for (int t = 0; t < m; ++t) rr += (-Qinv[i * m + t]) * Qux[t * n + j];
+            Kk[i * n + j] = rr;
         }
     }
 
@@ -308,35 +415,43 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
 }
 
 // ------------------------------------------------------------------
-// Whole backward pass (iLQRController.py:98-123) for one trajectory.
-// Writes d [S][m] and K [S][m*n]; returns deltaJ and max_k |d_k|_2 (with
-// NumPy's NaN propagation, as np.max(np.linalg.norm(d, axis=1)) has).
+// Whole backward pass (iLQRController.py:98-123) for one trajectory per lane.
+// All 64 lanes of the wavefront call it together; a lane without a trajectory
+// (`active` false) only helps the others.  Writes d [S][m] and K [S][m*n];
+// returns deltaJ and max_k |d_k|_2 (with NumPy's NaN propagation, as
+// np.max(np.linalg.norm(d, axis=1)) has).  Returns false on LinAlgError.
 // ------------------------------------------------------------------
 template <class M>
 __device__ inline bool backward_pass(const double* par, const CLane& X, const CLane& U, const Lane& D, const Lane& K,
-                                     int S, double& deltaJ, double& dmax, int& regu_rounds, double& maxq)
+                                     int S, double& deltaJ, double& dmax, int& regu_rounds, int& regu_stages,
+                                     double& maxq, bool active, double* lds)
 {
     constexpr int n = M::NDX, m = M::NU, nx = M::NX;
     double Vx[n], Vxx[n * n], xk[nx], uk[m], dk[m], Kk[m * n];
     load_vec<nx>(X, S, xk);
     M::final(par, xk, Vx, Vxx);
     double redu = 0.0, best = -INFINITY;
-    bool anynan = false;
+    bool anynan = false, ok = true;
     for (int k = S - 1; k >= 0; --k) {
         load_vec<nx>(X, k, xk);
         load_vec<m>(U, k, uk);
-        if (!backward_stage<M>(par, xk, uk, Vx, Vxx, dk, Kk, redu, regu_rounds, maxq)) return false;
-        store_vec<m>(D, k, dk);
-        store_vec<m * n>(K, k, Kk);
-        double s = 0.0;
-        for (int i = 0; i < m; ++i) s += dk[i] * dk[i];
-        double r = sqrt(s);
-        anynan = anynan || (r != r);
-        best = (r > best) ? r : best;
+        const bool alive = active && ok;
+        const bool good = backward_stage<M>(par, xk, uk, Vx, Vxx, dk, Kk, redu, regu_rounds, regu_stages, maxq, alive,
+                                            lds);
+        ok = ok && good;
+        if (alive && good) {
+            store_vec<m>(D, k, dk);
+            store_vec<m * n>(K, k, Kk);
+            double s = 0.0;
+            for (int i = 0; i < m; ++i) s += dk[i] * dk[i];
+            double r = sqrt(s);
+            anynan = anynan || (r != r);
+            best = (r > best) ? r : best;
+        }
     }
     deltaJ = redu;
     dmax = anynan ? NAN : best;
-    return true;
+    return ok;
 }
 
 // ------------------------------------------------------------------
@@ -368,14 +483,14 @@ __device__ inline double rollout_cost(const double* par, const double* x0, const
 // (:64): u_new = u + alpha d + K dx, x_new = f(x_new, u_new).  Candidate
 // trajectory is written to Xn/Un; its cost is returned.
 // ------------------------------------------------------------------
-template <class M>
+template <class M, bool WRITE = true>
 __device__ inline double forward_pass(const double* par, const CLane& X, const CLane& U, const CLane& D,
                                       const CLane& K, double alpha, const Lane& Xn, const Lane& Un, int S)
 {
     constexpr int n = M::NDX, m = M::NU, nx = M::NX;
     double xn[nx], xo[nx], xnext[nx], u[m], d[m], Kk[m * n], dx[n], un[m];
     load_vec<nx>(X, 0, xn);
-    store_vec<nx>(Xn, 0, xn);
+    if (WRITE) store_vec<nx>(Xn, 0, xn);
     double total = 0.0;
     for (int k = 0; k < S; ++k) {
         load_vec<nx>(X, k, xo);
@@ -388,14 +503,22 @@ __device__ inline double forward_pass(const double* par, const CLane& X, const C
             for (int t = 0; t < n; ++t) s += Kk[i * n + t] * dx[t];
             un[i] = (u[i] + alpha * d[i]) + s;
         }
-        store_vec<m>(Un, k, un);
+        if (WRITE) store_vec<m>(Un, k, un);
         total += M::cost_stage(par, xn, un);
         M::dynamics(par, xn, un, xnext);
         for (int i = 0; i < nx; ++i) xn[i] = xnext[i];
-        store_vec<nx>(Xn, k + 1, xn);
+        if (WRITE) store_vec<nx>(Xn, k + 1, xn);
     }
     total += M::cost_final(par, xn);
     return total;
+}
+
+// The same evaluation without storing the candidate (cost only).
+template <class M>
+__device__ inline double forward_cost(const double* par, const CLane& X, const CLane& U, const CLane& D,
+                                      const CLane& K, double alpha, int S)
+{
+    return forward_pass<M, false>(par, X, U, D, K, alpha, Lane{nullptr, 0}, Lane{nullptr, 0}, S);
 }
 
 }  // namespace ilqr

@@ -74,6 +74,7 @@ typedef struct {
     int32_t *status;     /* ILQR_EXIT_* */
     int32_t *regu_rounds;/* total regularisation rounds            (iLQRController.py:110-115) */
     int32_t *ls_total;   /* total forward-pass evaluations         (iLQRController.py:61-64) */
+    int32_t *regu_stages;/* backward stages that needed at least one regularisation round */
     int32_t *ls_evals;   /* trace: line-search evaluations of iteration it */
     uint8_t *accepted;   /* trace: 1 if the search of iteration it was accepted (:69) */
     double *J_trace;     /* trace: Jn after the search of iteration it (:79) */

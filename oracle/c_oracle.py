@@ -22,6 +22,7 @@ INFO_DTYPE = np.dtype([
     ("J", "<f8", (TRACE_MAX,)), ("deltaJ", "<f8", (TRACE_MAX,)),
     ("ls_evals", "<i4", (TRACE_MAX,)), ("accepted", "u1", (TRACE_MAX,)),
     ("iters", "<i4"), ("status", "<i4"), ("regu_rounds", "<i4"), ("ls_total", "<i4"),
+    ("regu_stages", "<i4"), ("pad_", "<i4"),
 ], align=True)
 
 

@@ -286,7 +286,6 @@ static int backward_pass(const ilqr_oracle_model *M, const double *par, const do
         Quu[ILQR_MAX_NU * ILQR_MAX_NU];
     double Q[(ILQR_MAX_NDX + ILQR_MAX_NU) * (ILQR_MAX_NDX + ILQR_MAX_NU)],
         W[(ILQR_MAX_NDX + ILQR_MAX_NU) * (ILQR_MAX_NDX + ILQR_MAX_NU)];
-    double T[ILQR_MAX_NDX * ILQR_MAX_NDX];
     double redu = 0.0;
 
     M->final_derivs(par, x + S * nx, Vx, Vxx);
@@ -294,8 +293,19 @@ static int backward_pass(const ilqr_oracle_model *M, const double *par, const do
         const double *xk = x + k * nx, *uk = u + k * nu;
         M->stage_derivs(par, xk, uk, lx, lu, lxx, lux, luu, fx, fu);
         M->q_terms(M, par, xk, lx, lu, lxx, lux, luu, fx, fu, Vx, Vxx, Qx, Qu, Qxx, Qux, Quu);
-        double regu = 0.1;
+        /* regularisation loop, iLQRController.py:106-115:
+         *   while any(eigvals(Q) < 0): Q += (regu*[fx fu])'[fx fu]; regu *= 2   with regu = 0.1 * 2^r.
+         * Because regu is 0.1 times a power of two, the r-th update is exactly 2^r * P0 with
+         * P0 = (0.1*[fx fu])'[fx fu] evaluated once in the reference's operation order.
+         * Rounds 1..ILQR_REGU_EXACT accumulate those updates one by one, exactly like the
+         * reference.  Beyond that (only ill-conditioned solves get there) the accumulated
+         * matrix is formed directly, Q(r) = Q(EXACT) + (2^r - 2^EXACT) * P0, which equals the
+         * running sum up to rounding; the scan over r and the stopping rule are unchanged. */
         full_hessian(Qxx, Qux, Quu, Q, n, nu);
+        int r = 0;
+        int have_p = 0;
+        double Pxx[ILQR_MAX_NDX * ILQR_MAX_NDX], Pux[ILQR_MAX_NU * ILQR_MAX_NDX], Puu[ILQR_MAX_NU * ILQR_MAX_NU];
+        double Bxx[ILQR_MAX_NDX * ILQR_MAX_NDX], Bux[ILQR_MAX_NU * ILQR_MAX_NDX], Buu[ILQR_MAX_NU * ILQR_MAX_NU];
         for (;;) {
             for (int i = 0; i < w * w; ++i) {
                 double a = fabs(Q[i]);
@@ -304,28 +314,46 @@ static int backward_pass(const ilqr_oracle_model *M, const double *par, const do
             int neg = ilqr_oracle_has_negative_eig(Q, w, W);
             if (neg < 0) return -1;
             if (!neg) break;
-            /* Q_xx += (regu f_x^T) f_x etc., iLQRController.py:111-115 */
-            for (int i = 0; i < n; ++i)
-                for (int j = 0; j < n; ++j) {
-                    double s = 0.0;
-                    for (int t = 0; t < n; ++t) s += (regu * fx[t * n + i]) * fx[t * n + j];
-                    T[i * n + j] = s;
+            if (!have_p) {
+                have_p = 1;
+                info->regu_stages += 1;
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j) {
+                        double s = 0.0;
+                        for (int t = 0; t < n; ++t) s += (0.1 * fx[t * n + i]) * fx[t * n + j];
+                        Pxx[i * n + j] = s;
+                    }
+                for (int i = 0; i < nu; ++i) {
+                    for (int j = 0; j < nu; ++j) {
+                        double s = 0.0;
+                        for (int t = 0; t < n; ++t) s += (0.1 * fu[t * nu + i]) * fu[t * nu + j];
+                        Puu[i * nu + j] = s;
+                    }
+                    for (int j = 0; j < n; ++j) {
+                        double s = 0.0;
+                        for (int t = 0; t < n; ++t) s += (0.1 * fu[t * nu + i]) * fx[t * n + j];
+                        Pux[i * n + j] = s;
+                    }
                 }
-            for (int i = 0; i < n * n; ++i) Qxx[i] += T[i];
-            for (int i = 0; i < nu; ++i)
-                for (int j = 0; j < nu; ++j) {
-                    double s = 0.0;
-                    for (int t = 0; t < n; ++t) s += (regu * fu[t * nu + i]) * fu[t * nu + j];
-                    Quu[i * nu + j] += s;
+            }
+            if (r < ILQR_REGU_EXACT) {
+                const double pw = ldexp(1.0, r);
+                for (int i = 0; i < n * n; ++i) Qxx[i] += pw * Pxx[i];
+                for (int i = 0; i < nu * nu; ++i) Quu[i] += pw * Puu[i];
+                for (int i = 0; i < nu * n; ++i) Qux[i] += pw * Pux[i];
+                if (r + 1 == ILQR_REGU_EXACT) {
+                    memcpy(Bxx, Qxx, sizeof(double) * n * n);
+                    memcpy(Bux, Qux, sizeof(double) * nu * n);
+                    memcpy(Buu, Quu, sizeof(double) * nu * nu);
                 }
-            for (int i = 0; i < nu; ++i)
-                for (int j = 0; j < n; ++j) {
-                    double s = 0.0;
-                    for (int t = 0; t < n; ++t) s += (regu * fu[t * nu + i]) * fx[t * n + j];
-                    Qux[i * n + j] += s;
-                }
+            } else {
+                const double coef = ldexp(1.0, r + 1) - ldexp(1.0, ILQR_REGU_EXACT);
+                for (int i = 0; i < n * n; ++i) Qxx[i] = Bxx[i] + coef * Pxx[i];
+                for (int i = 0; i < nu * nu; ++i) Quu[i] = Buu[i] + coef * Puu[i];
+                for (int i = 0; i < nu * n; ++i) Qux[i] = Bux[i] + coef * Pux[i];
+            }
             full_hessian(Qxx, Qux, Quu, Q, n, nu);
-            regu *= 2.0;
+            r += 1;
             info->regu_rounds += 1;
         }
         double *dk = d + k * nu, *Kk = K + k * nu * n;

@@ -7,6 +7,8 @@
 #define ILQR_MAX_NDX 16
 #define ILQR_MAX_NU 4
 #define ILQR_TRACE_MAX 64
+/* regularisation rounds accumulated one by one, as the reference does (see backward_pass) */
+#define ILQR_REGU_EXACT 12
 #ifndef ILQR_PIVOT_TOL
 #define ILQR_PIVOT_TOL 1e-13
 #endif
@@ -53,6 +55,8 @@ typedef struct {
     int32_t status;                  /* ILQR_EXIT_* */
     int32_t regu_rounds;             /* total regularisation rounds */
     int32_t ls_total;                /* total forward-pass evaluations */
+    int32_t regu_stages;             /* backward stages that needed regularisation */
+    int32_t pad_;
 } ilqr_oracle_info;
 
 int ilqr_oracle_solve(const ilqr_oracle_model *M, const double *par, int N, int max_iter, int max_ls, double d_tol,
