@@ -16,6 +16,7 @@ MODEL_CAR, MODEL_ACROBOT, MODEL_QUAD_EA, MODEL_QUAD_QUAT = 0, 1, 2, 3
 EXIT_DTOL, EXIT_SMALL_DELTAJ, EXIT_MAXITER, EXIT_LINALG = 0, 1, 2, 3
 EXIT_NAMES = {0: "d_tol", 1: "deltaJ<1", 2: "max_iter", 3: "linalg_error"}
 FLAG_PARALLEL_LS = 1
+FLAG_LS_SEQUENTIAL = 2
 
 EXPORTS = ("ilqr_model_info", "ilqr_workspace_bytes", "ilqr_solve_batch", "ilqr_rollout_cost",
            "ilqr_model_eval", "ilqr_mpc_advance", "ilqr_last_error", "ilqr_version")

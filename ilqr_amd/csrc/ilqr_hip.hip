@@ -140,7 +140,7 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
 
 struct WsLayout {
     size_t XA, XB, UA, UB, D, K, dJ, J0, J, dmax, maxq, iters, status, regu_rounds, regu_stages, ls_total, idA, idB,
-        ls_slot, ls_dest, bt, cnt, total;
+        ls_slot, ls_dest, bt, bt2, cnt, total;
 };
 WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
 {
@@ -156,8 +156,8 @@ WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
     w.iters = take(cap * 4); w.status = take(cap * 4); w.regu_rounds = take(cap * 4); w.regu_stages = take(cap * 4);
     w.ls_total = take(cap * 4);
     w.idA = take(cap * 4); w.idB = take(cap * 4); w.ls_slot = take(cap * 4); w.ls_dest = take(cap * 4);
-    w.bt = take(cap * 4);
-    w.cnt = take(64);
+    w.bt = take(cap * 4); w.bt2 = take(cap * 4);
+    w.cnt = take(64 * 4);
     w.total = off;
     return w;
 }
@@ -190,7 +190,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     a.XA = (double*)(ws + w.XA); a.XB = (double*)(ws + w.XB); a.UA = (double*)(ws + w.UA); a.UB = (double*)(ws + w.UB);
     a.D = (double*)(ws + w.D); a.K = (double*)(ws + w.K); a.dJ = (double*)(ws + w.dJ);
     a.idA = (int32_t*)(ws + w.idA); a.idB = (int32_t*)(ws + w.idB);
-    a.ls_slot = (int32_t*)(ws + w.ls_slot); a.ls_dest = (int32_t*)(ws + w.ls_dest); a.bt = (int32_t*)(ws + w.bt);
+    a.ls_slot = (int32_t*)(ws + w.ls_slot); a.ls_dest = (int32_t*)(ws + w.ls_dest); a.bt = (int32_t*)(ws + w.bt); a.bt2 = (int32_t*)(ws + w.bt2);
     a.cnt = (int32_t*)(ws + w.cnt);
 
     hipLaunchKernelGGL(pipe_init_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
@@ -202,13 +202,16 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
         HIP_TRY(hipGetLastError());
         return ILQR_OK;
     }
-    const bool parallel_ls = (a.flags & ILQR_FLAG_PARALLEL_LS) && a.max_ls >= 2 && a.max_ls - 1 <= 64;
-    int32_t h[3];
+    // line-search schedule: evaluation 1 for everybody, evaluations 2..seq_levels one launch each over the
+    // compacted list of trajectories still searching, then every remaining candidate side by side
+    const int seq_levels = (a.flags & ILQR_FLAG_LS_SEQUENTIAL) ? a.max_ls
+                         : (a.flags & ILQR_FLAG_PARALLEL_LS) ? 1 : 3;
+    int32_t h[4];
     long count = a.B;
     for (int iter = 1; iter <= a.max_iter && count > 0; ++iter) {
         a.count = (int)count;
         a.iter = iter;
-        HIP_TRY(hipMemsetAsync(a.cnt, 0, 3 * sizeof(int32_t), st));
+        HIP_TRY(hipMemsetAsync(a.cnt, 0, 64 * sizeof(int32_t), st));
         hipLaunchKernelGGL(pipe_backward_kernel<M>, dim3(blocks_for(count, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h, a.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -219,16 +222,25 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h + 2, a.cnt + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            const long nbt = h[2];
-            if (nbt > 0) {
-                if (parallel_ls) {
-                    const int per_wave = 64 / (a.max_ls - 1);
-                    hipLaunchKernelGGL(pipe_backtrack_parallel_kernel<M>, dim3(blocks_for(nbt, per_wave)),
-                                       dim3(PIPE_WG), 0, st, a);
-                } else {
-                    hipLaunchKernelGGL(pipe_backtrack_kernel<M>, dim3(blocks_for(nbt, PIPE_WG)), dim3(PIPE_WG), 0, st,
-                                       a);
+            long bound = h[2];                    // trajectories whose first candidate was rejected
+            int32_t *lin = a.bt, *lout = a.bt2;
+            int ls = 2;
+            double alpha = 0.5;
+            for (; bound > 0 && ls <= a.max_ls && (ls <= seq_levels || a.max_ls - ls + 1 > 64); ++ls, alpha *= 0.5) {
+                hipLaunchKernelGGL(pipe_forward_level_kernel<M>, dim3(blocks_for(bound, PIPE_WG)), dim3(PIPE_WG), 0, st,
+                                   a, lin, a.cnt + ls, lout, a.cnt + ls + 1, ls, alpha);
+                HIP_TRY(hipGetLastError());
+                int32_t* t = lin; lin = lout; lout = t;
+                if (ls == seq_levels || (ls % 4) == 0) {     // tighten the bound now and then
+                    HIP_TRY(hipMemcpyAsync(h + 3, a.cnt + ls + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    bound = h[3];
                 }
+            }
+            if (bound > 0 && ls <= a.max_ls) {
+                const int per_wave = 64 / (a.max_ls - ls + 1);
+                hipLaunchKernelGGL(pipe_backtrack_parallel_kernel<M>, dim3(blocks_for(bound, per_wave)), dim3(PIPE_WG),
+                                   0, st, a, lin, a.cnt + ls, ls);
                 HIP_TRY(hipGetLastError());
             }
         }

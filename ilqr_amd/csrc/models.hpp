@@ -25,7 +25,6 @@ namespace ilqr {
 // Loop-unrolling policy: small plants keep every matrix in registers (fully
 // unrolled loops, compile-time indices); the 12-state plants keep loops rolled
 // so their matrices live in per-lane private memory.
-#define ILQR_UNROLL_IF(cond) _Pragma("unroll")
 
 template <int NX>
 __device__ __forceinline__ void diff_sub(const double* s, const double* r, double* dx)
@@ -38,6 +37,10 @@ __device__ __forceinline__ void diff_sub(const double* s, const double* r, doubl
 struct CarModel {
     static constexpr int NX = 5, NU = 2, NDX = 5, NPAR = 2;
     static constexpr bool UNROLL = true;
+#ifndef ILQR_CAR_BACKWARD_WAVES
+#define ILQR_CAR_BACKWARD_WAVES 2
+#endif
+    static constexpr int BACKWARD_WAVES = ILQR_CAR_BACKWARD_WAVES;   // waves per SIMD the backward kernel is built for
     __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
     {
         car_gen_dynamics(par, x, u, xn);
@@ -145,6 +148,7 @@ struct QuadraticRK4Model {
     static constexpr int NX = NX_, NU = NU_, NDX = NX_;
     static constexpr int NPAR = 1 + 2 * NX * NX + NU * NU + NX + NU;
     static constexpr bool UNROLL = UNROLL_;
+    static constexpr int BACKWARD_WAVES = 1;
     __device__ static const double* Qm(const double* p) { return p + 1; }
     __device__ static const double* Qf(const double* p) { return p + 1 + NX * NX; }
     __device__ static const double* Rm(const double* p) { return p + 1 + 2 * NX * NX; }
@@ -225,6 +229,7 @@ using QuadEAModel = QuadraticRK4Model<12, 4, false, quad_ea_gen_xdot, quad_ea_ge
 struct QuadQuatModel {
     static constexpr int NX = 13, NU = 4, NDX = 12, NPAR = 1 + 12 + 12 + 4 + 13 + 4;
     static constexpr bool UNROLL = false;
+    static constexpr int BACKWARD_WAVES = 1;
     __device__ static const double* qd(const double* p) { return p + 1; }
     __device__ static const double* qfd(const double* p) { return p + 13; }
     __device__ static const double* rd(const double* p) { return p + 25; }

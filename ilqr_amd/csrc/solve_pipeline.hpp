@@ -11,7 +11,8 @@
 //   init      rollout + cost of the initial guess            (:27-34)
 //   backward  Riccati sweep, exit tests, slot allocation      (:43-51, :98-123)
 //   forward1  first line-search candidate, alpha = 1          (:60-68, :87-96)
-//   backtrack remaining candidates for the few that need them (:60-68)
+//   level L   candidate number L (alpha = 0.5^(L-1)) for those still searching, one launch per level
+//   parallel  all remaining candidates side by side, first stopping one wins (:60-68)
 //
 // State of a running trajectory (x, u) lives in one of two slot-indexed
 // structure-of-arrays buffers; the forward pass, which has to write the new
@@ -50,8 +51,9 @@ struct Pipe {
     double *tr_J, *tr_dJ;
     // slot-indexed buffers
     double *XA, *XB, *UA, *UB, *D, *K, *dJ;
-    int32_t *idA, *idB, *ls_slot, *ls_dest, *bt;
-    int32_t* cnt;              // [0] slots handed out in B, [1] line-search entries, [2] backtrack entries
+    int32_t *idA, *idB, *ls_slot, *ls_dest, *bt, *bt2;
+    int32_t* cnt;              // [0] slots handed out in B, [1] line-search entries, [1 + L] entries that go on
+                               // after evaluation number L (L = 1, 2, ...)
     int count;                 // running trajectories = used slots of buffer A
     int iter;                  // 1-based number of the iteration being run
 };
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_finish_all_kernel(Pipe a, int st
 
 // ---------------------------------------------------------------- backward
 template <class M>
-__global__ __launch_bounds__(PIPE_WG) void pipe_backward_kernel(Pipe a)
+__global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kernel(Pipe a)
 {
     __shared__ double lds[QPack<M::NDX, M::NU>::LDS_DOUBLES];
     const int s0 = blockIdx.x * PIPE_WG + threadIdx.x;
@@ -221,55 +223,68 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_forward1_kernel(Pipe a)
     if (need_bt) a.bt[q] = j;
 }
 
-// ---------------------------------------------------------------- backtracking, one lane per trajectory
+// ---------------------------------------------------------------- one more candidate for the entries of a list
+// Evaluation number `ls` (alpha = 0.5^(ls-1)) for every entry of `list_in`;
+// entries whose search goes on are appended to `list_out`.  Each level is one
+// launch over a compacted list, so a wavefront never waits for a trajectory
+// that needs more candidates than its neighbours.
 template <class M>
-__global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_kernel(Pipe a)
+__global__ __launch_bounds__(PIPE_WG) void pipe_forward_level_kernel(Pipe a, const int32_t* __restrict__ list_in,
+                                                                     const int32_t* __restrict__ n_in,
+                                                                     int32_t* __restrict__ list_out,
+                                                                     int32_t* __restrict__ n_out, int ls, double alpha)
 {
     const int q = blockIdx.x * PIPE_WG + threadIdx.x;
-    if (q >= a.cnt[2]) return;
-    const int j = a.bt[q];
-    const int s = a.ls_slot[j], dest = a.ls_dest[j], id = a.idA[s];
-    const CLane X{a.XA + s, a.cap}, U{a.UA + s, a.cap}, D{a.D + s, a.cap}, K{a.K + s, a.cap};
-    const Dest d = make_dest(a, dest, id);
-    const double J = a.J[id], deltaJ = a.dJ[s];
-    int ls = 1;
-    double alpha = 0.5, Jn = 0.0;
-    bool complete = false, abandon = false;
-    while (!complete && !abandon) {                                                    // :60-68
-        ls += 1;
-        Jn = forward_pass<M>(a.par, X, U, D, K, alpha, d.X, d.U, a.N - 1);
-        complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);
-        abandon = (Jn != Jn) || (ls >= a.max_ls);
-        alpha *= 0.5;
+    bool more = false;
+    int j = 0;
+    if (q < *n_in) {
+        j = list_in[q];
+        const int s = a.ls_slot[j], dest = a.ls_dest[j], id = a.idA[s];
+        const CLane X{a.XA + s, a.cap}, U{a.UA + s, a.cap};
+        const Dest d = make_dest(a, dest, id);
+        const double J = a.J[id], deltaJ = a.dJ[s];
+        const double Jn = forward_pass<M>(a.par, X, U, CLane{a.D + s, a.cap}, CLane{a.K + s, a.cap}, alpha, d.X, d.U,
+                                          a.N - 1);
+        const bool complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);   // :66
+        const bool abandon = (Jn != Jn) || (ls >= a.max_ls);                           // :67
+        if (complete || abandon) {
+            if (!complete) copy_traj<M>(X, U, d.X, d.U, a.N);
+            record_search(a, id, ls, complete, Jn);
+        } else {
+            more = true;
+        }
     }
-    if (!complete) copy_traj<M>(X, U, d.X, d.U, a.N);
-    record_search(a, id, ls, complete, Jn);
+    const int o = wave_append(more, n_out);
+    if (more) list_out[o] = j;
 }
 
-// ---------------------------------------------------------------- backtracking, alphas side by side
-// G = max_ls - 1 lanes per trajectory, lane g evaluates alpha = 0.5^(g+1), i.e.
-// line-search evaluation number g + 2.  The search result is that of the first
-// evaluation, in order, at which the sequential loop would have stopped (:66-67);
-// a wave-wide ballot finds it, and the lane that owns it re-runs its forward
-// pass to write the accepted trajectory.
+// ---------------------------------------------------------------- remaining candidates side by side
+// G = max_ls - first_ls + 1 lanes per trajectory, lane g evaluates line-search
+// evaluation number first_ls + g (alpha = 0.5^(first_ls + g - 1)) without
+// storing it.  The search result is that of the first evaluation, in order, at
+// which the sequential loop would have stopped (:66-67); a wave-wide ballot
+// finds it, and the lane that owns it re-runs its forward pass to write the
+// accepted trajectory.
 template <class M>
-__global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_parallel_kernel(Pipe a)
+__global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_parallel_kernel(Pipe a, const int32_t* __restrict__ list_in,
+                                                                          const int32_t* __restrict__ n_in,
+                                                                          int first_ls)
 {
-    const int G = a.max_ls - 1;                    // candidates per trajectory, 1 <= G <= 64
+    const int G = a.max_ls - first_ls + 1;         // candidates per trajectory, 1 <= G <= 64
     const int per_wave = 64 / G;
     const int lane = threadIdx.x & 63;
     const int grp = lane / G, g = lane - grp * G;
     const int q = blockIdx.x * per_wave + grp;
-    const bool live = grp < per_wave && q < a.cnt[2];
-    int j = 0, s = 0, dest = -1, id = 0;
-    double J = 0.0, deltaJ = 0.0, Jn = 0.0, alpha = 0.5;
+    const bool live = grp < per_wave && q < *n_in;
+    int s = 0, dest = -1, id = 0;
+    double J = 0.0, deltaJ = 0.0, Jn = 0.0, alpha = 1.0;
     bool stop = false, complete = false;
-    const int ls = g + 2;
+    const int ls = first_ls + g;
     if (live) {
-        j = a.bt[q];
+        const int j = list_in[q];
         s = a.ls_slot[j]; dest = a.ls_dest[j]; id = a.idA[s];
         J = a.J[id]; deltaJ = a.dJ[s];
-        for (int i = 0; i < g; ++i) alpha *= 0.5;
+        for (int i = 1; i < ls; ++i) alpha *= 0.5;
         Jn = forward_cost<M>(a.par, CLane{a.XA + s, a.cap}, CLane{a.UA + s, a.cap}, CLane{a.D + s, a.cap},
                              CLane{a.K + s, a.cap}, alpha, a.N - 1);
         complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);
@@ -277,7 +292,6 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_parallel_kernel(Pipe a
     }
     const unsigned long long stops = __ballot(stop);
     if (!live) return;
-    // first stopping lane of my group
     const unsigned long long gmask = ((G >= 64) ? ~0ull : ((1ull << G) - 1ull)) << (grp * G);
     const int first = __ffsll((long long)(stops & gmask)) - 1;     // always exists: the last candidate stops
     if (lane != first) return;

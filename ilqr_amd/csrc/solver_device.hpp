@@ -42,78 +42,7 @@ __device__ __forceinline__ void store_vec(const Lane& a, int row, const double* 
     for (int c = 0; c < C; ++c) a.st(row * C + c, v[c]);
 }
 
-// ------------------------------------------------------------------
-// `np.any(np.linalg.eigvals(Q) < 0)` of iLQRController.py:110, decided by an
-// unpivoted right-looking LDL' of the lower triangle of
-// Q = [[Qxx, Qux'], [Qux, Quu]] with deflation of zero pivots:
-//   pivot < 0 -> negative eigenvalue; zero pivot with a non-zero column below
-//   -> indefinite; zero pivot with a zero column -> zero eigenvalue, skip.
-// A pivot that has cancelled to within PIVOT_TOL of its diagonal entry is
-// rounding noise and is treated as zero (without this, a Q that is dominated
-// by regu*[fx fu]'[fx fu], which is rank deficient, keeps the same noise sign
-// through every further doubling of regu).
-// Returns 1 (negative eigenvalue), 0 (none), -1 (Q not finite: NumPy raises).
-// ------------------------------------------------------------------
 constexpr double PIVOT_TOL = 1e-13;
-
-template <int n, int m>
-__device__ inline int has_negative_eig(const double* Qxx, const double* Qux, const double* Quu, double& maxq)
-{
-    constexpr int w = n + m;
-    double W[w * w];
-    bool finite = true;
-    double mq = maxq;
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            double v = Qxx[i * n + j];
-            double a = fabs(v);
-            finite = finite && (a <= DBL_MAX);
-            mq = (a > mq) ? a : mq;
-            if (j <= i) W[i * w + j] = v;
-        }
-    for (int i = 0; i < m; ++i) {
-        for (int j = 0; j < n; ++j) {
-            double v = Qux[i * n + j];
-            double a = fabs(v);
-            finite = finite && (a <= DBL_MAX);
-            mq = (a > mq) ? a : mq;
-            W[(n + i) * w + j] = v;
-        }
-        for (int j = 0; j < m; ++j) {
-            double v = Quu[i * m + j];
-            double a = fabs(v);
-            finite = finite && (a <= DBL_MAX);
-            mq = (a > mq) ? a : mq;
-            if (j <= i) W[(n + i) * w + n + j] = v;
-        }
-    }
-    maxq = mq;
-    if (!finite) return -1;
-    int result = 0;
-    for (int j = 0; j < w; ++j) {
-        const double p = W[j * w + j];
-        const double ajj = (j < n) ? Qxx[j * n + j] : Quu[(j - n) * m + (j - n)];
-        const double thr = PIVOT_TOL * fabs(ajj);
-        if (p < -thr) { result = 1; break; }
-        if (p <= thr) {
-            // (numerically) zero pivot: a PSD matrix then has a (numerically) zero
-            // column, |S_ij|^2 <= S_ii S_jj; anything larger is indefinite
-            bool nz = false;
-            for (int i = j + 1; i < w; ++i) {
-                double c = W[i * w + j];
-                nz = nz || (c * c > 4.0 * thr * fabs(W[i * w + i]));
-            }
-            if (nz) { result = 1; break; }
-            continue;
-        }
-        double pinv = 1.0 / p;
-        for (int i = j + 1; i < w; ++i) {
-            double lij = W[i * w + j] * pinv;
-            for (int k = j + 1; k <= i; ++k) W[i * w + k] -= lij * W[k * w + j];
-        }
-    }
-    return result;
-}
 
 // np.linalg.inv of an m x m matrix (m <= 4) by Gauss-Jordan with row
 // pivoting.  Returns false when a pivot is exactly zero (NumPy: LinAlgError).
@@ -168,191 +97,435 @@ __device__ inline bool inv_small(const double* A, double* Ainv)
 }
 
 // ------------------------------------------------------------------
+// Symmetric storage.  V_xx and the Q-function Hessian are symmetric in exact
+// arithmetic; the kernels keep their lower triangles only (the reference carries
+// both triangles, which differ by rounding).  Packed lower triangle of a k x k
+// matrix: entry (i, j), i >= j, sits at i (i + 1) / 2 + j.  The full Hessian
+// [[Qxx, Qux'], [Qux, Quu]] is packed in the order [x (n); u (m)].
+// ------------------------------------------------------------------
+__device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+__device__ __forceinline__ constexpr int sym(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }
+
+#define ILQR_PRAGMA(x) _Pragma(#x)
+// small plants: every matrix in registers, which needs compile-time indices
+// everywhere (UF = full unroll); 12-state plants keep their loops rolled (UF = 1)
+#define ILQR_UNROLL ILQR_PRAGMA(unroll UF)
+
+// Q-function terms of one stage from the plant's dense stage() derivatives
+// (control/models/model.py:45-53), for symmetric V_xx.  aux = [fx (n*n), fu (n*m)].
+template <class M>
+struct DenseTerms {
+    static constexpr int n = M::NDX, m = M::NU, w = n + m;
+    static constexpr int AUX = n * n + n * m;
+    static constexpr int UF = M::UNROLL ? 64 : 1;
+    __device__ static void backward_terms(const double* par, const double* x, const double* u, const double* Vx,
+                                          const double* VL, double* Qx, double* Qu, double* QL, double* aux)
+    {
+        double lx[n], lu[m], lxx[n * n], lux[m * n], luu[m * m];
+        double* const fx = aux;
+        double* const fu = aux + n * n;
+        M::stage(par, x, u, lx, lu, lxx, lux, luu, fx, fu);
+        ILQR_UNROLL
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+            ILQR_UNROLL
+            for (int t = 0; t < n; ++t) s += fx[t * n + i] * Vx[t];
+            Qx[i] = lx[i] + s;
+        }
+        ILQR_UNROLL
+        for (int i = 0; i < m; ++i) {
+            double s = 0.0;
+            ILQR_UNROLL
+            for (int t = 0; t < n; ++t) s += fu[t * m + i] * Vx[t];
+            Qu[i] = lu[i] + s;
+        }
+        {
+            double FtV[n * n];     // f_x' V_xx
+            ILQR_UNROLL
+            for (int i = 0; i < n; ++i)
+                ILQR_UNROLL
+                for (int j = 0; j < n; ++j) {
+                    double s = 0.0;
+                    ILQR_UNROLL
+                    for (int t = 0; t < n; ++t) s += fx[t * n + i] * VL[sym(t, j)];
+                    FtV[i * n + j] = s;
+                }
+            ILQR_UNROLL
+            for (int i = 0; i < n; ++i)
+                ILQR_UNROLL
+                for (int j = 0; j <= i; ++j) {
+                    double s = 0.0;
+                    ILQR_UNROLL
+                    for (int t = 0; t < n; ++t) s += FtV[i * n + t] * fx[t * n + j];
+                    QL[tri(i, j)] = lxx[i * n + j] + s;
+                }
+        }
+        {
+            double GtV[m * n];     // f_u' V_xx
+            ILQR_UNROLL
+            for (int i = 0; i < m; ++i)
+                ILQR_UNROLL
+                for (int j = 0; j < n; ++j) {
+                    double s = 0.0;
+                    ILQR_UNROLL
+                    for (int t = 0; t < n; ++t) s += fu[t * m + i] * VL[sym(t, j)];
+                    GtV[i * n + j] = s;
+                }
+            ILQR_UNROLL
+            for (int i = 0; i < m; ++i) {
+                ILQR_UNROLL
+                for (int j = 0; j < n; ++j) {
+                    double s = 0.0;
+                    ILQR_UNROLL
+                    for (int t = 0; t < n; ++t) s += GtV[i * n + t] * fx[t * n + j];
+                    QL[tri(n + i, j)] = lux[i * n + j] + s;
+                }
+                ILQR_UNROLL
+                for (int j = 0; j <= i; ++j) {
+                    double s = 0.0;
+                    ILQR_UNROLL
+                    for (int t = 0; t < n; ++t) s += GtV[i * n + t] * fu[t * m + j];
+                    QL[tri(n + i, n + j)] = luu[i * m + j] + s;
+                }
+            }
+        }
+    }
+    // P = (0.1 [fx fu])'[fx fu], lower triangle, in the reference's operation order (iLQRController.py:111-113)
+    __device__ static void regu_p(const double* aux, double* PL)
+    {
+        const double* const fx = aux;
+        const double* const fu = aux + n * n;
+        ILQR_UNROLL
+        for (int i = 0; i < w; ++i)
+            ILQR_UNROLL
+            for (int j = 0; j <= i; ++j) {
+                double s = 0.0;
+                ILQR_UNROLL
+                for (int t = 0; t < n; ++t) {
+                    const double a = (i < n) ? fx[t * n + i] : fu[t * m + (i - n)];
+                    const double b = (j < n) ? fx[t * n + j] : fu[t * m + (j - n)];
+                    s += (0.1 * a) * b;
+                }
+                PL[tri(i, j)] = s;
+            }
+    }
+    __device__ static void final_sym(const double* par, const double* x, double* Vx, double* VL)
+    {
+        double Vxx[n * n];
+        M::final(par, x, Vx, Vxx);
+        ILQR_UNROLL
+        for (int i = 0; i < n; ++i)
+            ILQR_UNROLL
+            for (int j = 0; j <= i; ++j) VL[tri(i, j)] = Vxx[i * n + j];
+    }
+};
+
+// Kinematic car: the same terms with the sparsity of f_x, f_u, l_xx folded in
+// offline (generated by tools/gen_models.py).  aux = the six state-dependent entries of f_x.
+struct CarSparseTerms {
+    static constexpr int AUX = 6;
+    __device__ static void backward_terms(const double* par, const double* x, const double* u, const double* Vx,
+                                          const double* VL, double* Qx, double* Qu, double* QL, double* aux)
+    {
+        car_gen_backward_terms(par, x, u, Vx, VL, Qx, Qu, QL, aux);
+    }
+    __device__ static void regu_p(const double* aux, double* PL) { car_gen_regu_p(aux, PL); }
+    __device__ static void final_sym(const double* par, const double* x, double* Vx, double* VL)
+    {
+        DenseTerms<CarModel>::final_sym(par, x, Vx, VL);
+    }
+};
+template <class M> struct TermsOf { using type = DenseTerms<M>; };
+template <> struct TermsOf<CarModel> { using type = CarSparseTerms; };
+
+// ------------------------------------------------------------------
+// `np.any(np.linalg.eigvals(Q) < 0)` of iLQRController.py:110, decided by an
+// unpivoted right-looking LDL' of the packed lower triangle L (destroyed):
+//   pivot < 0 -> negative eigenvalue; zero pivot with a non-zero column below
+//   -> indefinite; zero pivot with a zero column -> zero eigenvalue, skip.
+// A pivot that has cancelled to within PIVOT_TOL of the terms it is the
+// difference of (acc_j = |Q_jj| + sum_k |l_jk^2 d_k|) is rounding noise and is
+// treated as zero (without this, a Q dominated by regu*[fx fu]'[fx fu], which is
+// rank deficient, keeps the same noise sign through every further doubling of regu).
+// Returns 1 (negative eigenvalue), 0 (none), -1 (not finite: NumPy raises).
+// ------------------------------------------------------------------
+template <int w, int UF>
+__device__ inline int has_negative_eig_packed(double* L, double& maxq)
+{
+    constexpr int NL = w * (w + 1) / 2;
+    bool finite = true;
+    double mq = maxq;
+    double acc[w];      // |Q_jj| + sum_k |l_jk^2 d_k|: the size of the terms pivot j is the difference of
+    ILQR_UNROLL
+    for (int e = 0; e < NL; ++e) {
+        const double a = fabs(L[e]);
+        finite = finite && (a <= DBL_MAX);
+        mq = (a > mq) ? a : mq;
+    }
+    ILQR_UNROLL
+    for (int i = 0; i < w; ++i) acc[i] = fabs(L[tri(i, i)]);
+    maxq = mq;
+    if (!finite) return -1;
+    int result = 0;
+    bool done = false;
+    ILQR_UNROLL
+    for (int j = 0; j < w; ++j) {
+        if (!done) {
+            const double p = L[tri(j, j)];
+            const double thr = PIVOT_TOL * acc[j];
+            if (p < -thr) {
+                result = 1;
+                done = true;
+            } else if (p <= thr) {
+                bool nz = false;
+                ILQR_UNROLL
+                for (int i = j + 1; i < w; ++i) {
+                    const double c = L[tri(i, j)];
+                    nz = nz || (c * c > 4.0 * thr * fabs(L[tri(i, i)]));
+                }
+                if (nz) {
+                    result = 1;
+                    done = true;
+                }
+            } else {
+                const double pinv = 1.0 / p;
+                ILQR_UNROLL
+                for (int i = j + 1; i < w; ++i) {
+                    const double lij = L[tri(i, j)] * pinv;
+                    ILQR_UNROLL
+                    for (int k = j + 1; k <= i; ++k) L[tri(i, k)] -= lij * L[tri(k, j)];
+                    acc[i] += fabs(lij * L[tri(i, j)]);
+                }
+            }
+        }
+    }
+    return result;
+}
+
+// ------------------------------------------------------------------
 // Regularisation loop of iLQRController.py:106-115,
 //     regu = 0.1; while any(eigvals(Q) < 0): Q += (regu [fx fu])'[fx fu]; regu *= 2
 // Because regu is 0.1 times a power of two, the update of round r is exactly
-// 2^r * P with P = (0.1 [fx fu])'[fx fu] evaluated once in the reference's
-// operation order, so "after r rounds" is a matrix Q(r) every lane can build:
+// 2^r * P with P = (0.1 [fx fu])'[fx fu] evaluated once, so "after r rounds" is a
+// matrix Q(r) any lane can build:
 //   r <= REGU_EXACT : Q(r) = Q(r-1) + 2^(r-1) P, accumulated one by one as the reference does;
 //   r >  REGU_EXACT : Q(r) = Q(REGU_EXACT) + (2^r - 2^REGU_EXACT) P, the same sum up to rounding
 //                     (only ill-conditioned solves need more than ~8 rounds).
 // The result of the loop is the first r = 0, 1, 2, ... whose Q(r) has no negative eigenvalue.
 //
-// Execution: the first REGU_LOCKSTEP rounds run lane by lane.  A lane that
-// still fails then is "stuck" (typically ~50 rounds until regu swamps the
-// curvature); instead of making the other 63 trajectories of the wavefront
-// wait through its scan, the wavefront scans for it: the stuck lane publishes
-// Q(REGU_LOCKSTEP) and P in LDS, lane l tests Q(REGU_LOCKSTEP + 1 + l), a ballot
-// picks the first r that stops the scan, and that lane hands Q(r) back.
+// Execution.  Typically a few lanes of a wavefront need 1-8 rounds at a stage
+// and, in ill-conditioned solves, one needs ~50.  Running the loop lane by lane
+// makes 64 trajectories wait for the slowest, so the wavefront scans instead:
+//   group scan: up to 8 lanes that need regularisation publish Q(0) and P in
+//     LDS; lane 8g+c builds and tests Q(c+1) of trajectory g; the first passing
+//     c of each group is that trajectory's answer (plants with a small Hessian);
+//   stuck scan: a trajectory still failing after REGU_BASE rounds publishes
+//     Q(REGU_BASE) and P; lane l tests Q(REGU_BASE + 1 + l), then +64, ...
 // ------------------------------------------------------------------
-constexpr int REGU_LOCKSTEP = 4;
-constexpr int REGU_EXACT = 12;
+constexpr int REGU_BASE = 8;      // rounds covered by the group scan (or lane by lane for the big plants)
+constexpr int REGU_EXACT = 12;    // rounds accumulated one by one
+constexpr int REGU_GROUPS = 8;    // trajectories per group scan; REGU_GROUPS * REGU_BASE == 64
 
 template <int n, int m>
 struct QPack {
-    static constexpr int NQ = n * n + m * n + m * m;
-    static constexpr int LDS_DOUBLES = 2 * NQ + 4;      // per-wavefront record: Q, P, then {test result, r, max|Q|}
+    static constexpr int w = n + m;
+    static constexpr int NL = w * (w + 1) / 2;
+    static constexpr bool GROUP_SCAN = NL <= 36;
+    // per-wavefront LDS: Q and P of up to REGU_GROUPS trajectories, then one {test result, max|Q|} pair per lane
+    static constexpr int RES = (GROUP_SCAN ? REGU_GROUPS : 1) * 2 * NL;
+    static constexpr int LDS_DOUBLES = RES + 128;
 };
-
-// Q(r) for one entry, from q = Q(REGU_LOCKSTEP) and p = P
-__device__ __forceinline__ double regu_entry(double q, double p, int r, double coef)
-{
-    double pw = (double)(1 << REGU_LOCKSTEP);
-#pragma unroll
-    for (int i = REGU_LOCKSTEP; i < REGU_EXACT; ++i) {
-        q = (i < r) ? q + pw * p : q;        // pw * p is exact (power of two), so contraction cannot change it
-        pw *= 2.0;
-    }
-    return (r > REGU_EXACT) ? __dadd_rn(q, __dmul_rn(coef, p)) : q;
-}
 
 // ------------------------------------------------------------------
 // One stage of the backward Riccati sweep: iLQRController.py:103-122 with
 // Model.Q_terms (model.py:45-53), the regularisation loop (:106-115), _gains
 // (:125-129), _V_terms (:131-134) and _expected_cost_reduction (:136-137).
-// Vx/Vxx are updated in place; d_k and K_k are returned in dk/Kk.
+// Vx and VL (packed V_xx) are updated in place; d_k and K_k are returned.
 // Must be called by all 64 lanes of the wavefront together (`alive` = this
 // lane carries a trajectory); `lds` is the wavefront's QPack record.
 // Returns false on the LinAlgError cases.
 // ------------------------------------------------------------------
 template <class M>
-__device__ inline bool backward_stage(const double* par, const double* xk, const double* uk, double* Vx, double* Vxx,
+__device__ inline bool backward_stage(const double* par, const double* xk, const double* uk, double* Vx, double* VL,
                                       double* dk, double* Kk, double& redu, int& regu_rounds, int& regu_stages,
                                       double& maxq, bool alive, double* lds)
 {
-    constexpr int n = M::NDX, m = M::NU;
-    constexpr int NQ = QPack<n, m>::NQ;
-    double lx[n], lu[m], lxx[n * n], lux[m * n], luu[m * m], fx[n * n], fu[n * m];
-    M::stage(par, xk, uk, lx, lu, lxx, lux, luu, fx, fu);
+    using TR = typename TermsOf<M>::type;
+    constexpr int n = M::NDX, m = M::NU, w = n + m;
+    constexpr int NL = QPack<n, m>::NL;
+    constexpr int UF = M::UNROLL ? 64 : 1;
+    double Qx[n], Qu[m], QL[NL], aux[TR::AUX];
+    TR::backward_terms(par, xk, uk, Vx, VL, Qx, Qu, QL, aux);
 
-    double Qx[n], Qu[m], QQ[NQ];
-    double* const Qxx = QQ;
-    double* const Qux = QQ + n * n;
-    double* const Quu = QQ + n * n + m * n;
-    {
-        // Q_x = l_x + f_x' V_x ; Q_u = l_u + f_u' V_x
-        for (int i = 0; i < n; ++i) {
-            double s = 0.0;
-            for (int t = 0; t < n; ++t) s += fx[t * n + i] * Vx[t];
-            Qx[i] = lx[i] + s;
-        }
-        for (int i = 0; i < m; ++i) {
-            double s = 0.0;
-            for (int t = 0; t < n; ++t) s += fu[t * m + i] * Vx[t];
-            Qu[i] = lu[i] + s;
-        }
-        // Q_xx = l_xx + (f_x' V_xx) f_x ; Q_ux = l_ux + (f_u' V_xx) f_x ; Q_uu = l_uu + (f_u' V_xx) f_u
-        double FtV[n * n];
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) {
-                double s = 0.0;
-                for (int t = 0; t < n; ++t) s += fx[t * n + i] * Vxx[t * n + j];
-                FtV[i * n + j] = s;
-            }
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) {
-                double s = 0.0;
-                for (int t = 0; t < n; ++t) s += FtV[i * n + t] * fx[t * n + j];
-                Qxx[i * n + j] = lxx[i * n + j] + s;
-            }
-        double GtV[m * n];
-        for (int i = 0; i < m; ++i)
-            for (int j = 0; j < n; ++j) {
-                double s = 0.0;
-                for (int t = 0; t < n; ++t) s += fu[t * m + i] * Vxx[t * n + j];
-                GtV[i * n + j] = s;
-            }
-        for (int i = 0; i < m; ++i) {
-            for (int j = 0; j < n; ++j) {
-                double s = 0.0;
-                for (int t = 0; t < n; ++t) s += GtV[i * n + t] * fx[t * n + j];
-                Qux[i * n + j] = lux[i * n + j] + s;
-            }
-            for (int j = 0; j < m; ++j) {
-                double s = 0.0;
-                for (int t = 0; t < n; ++t) s += GtV[i * n + t] * fu[t * m + j];
-                Quu[i * m + j] = luu[i * m + j] + s;
-            }
-        }
-    }
-
-    // ---- regularisation, rounds 0..REGU_LOCKSTEP lane by lane
+    // ---- regularisation: round 0 test in every lane
     bool ok = true;
     int r = 0;
-    int neg = has_negative_eig<n, m>(Qxx, Qux, Quu, maxq);
-    ok = ok && (neg >= 0);
-    bool need = alive && (neg == 1);
-    double PP[NQ];
-    if (need) {
-        regu_stages += 1;
-        double* const Pxx = PP;
-        double* const Pux = PP + n * n;
-        double* const Puu = PP + n * n + m * n;
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) {
-                double s = 0.0;
-                for (int t = 0; t < n; ++t) s += (0.1 * fx[t * n + i]) * fx[t * n + j];
-                Pxx[i * n + j] = s;
+    bool need;
+    {
+        double L[NL];
+        ILQR_UNROLL
+        for (int e = 0; e < NL; ++e) L[e] = QL[e];
+        const int neg = has_negative_eig_packed<w, UF>(L, maxq);
+        ok = ok && (neg >= 0);
+        need = alive && (neg == 1);
+    }
+    if (need) regu_stages += 1;
+    const int lane = threadIdx.x & 63;
+    double* const res = lds + QPack<n, m>::RES;          // [64][2]
+    bool stuck_here = false;
+
+    if constexpr (QPack<n, m>::GROUP_SCAN) {
+        // ---- group scan: rounds 1..REGU_BASE of up to REGU_GROUPS trajectories at once
+        unsigned long long pend = __ballot(need);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        while (pend) {
+            const int rank = __popcll(pend & below);
+            const bool src = need && rank < REGU_GROUPS;
+            const int nsrc = min((int)__popcll(pend), REGU_GROUPS);
+            __syncthreads();
+            if (src) {
+                double PL[NL];
+                TR::regu_p(aux, PL);
+                ILQR_UNROLL
+                for (int e = 0; e < NL; ++e) {
+                    lds[rank * 2 * NL + e] = QL[e];
+                    lds[rank * 2 * NL + NL + e] = PL[e];
+                }
             }
-        for (int i = 0; i < m; ++i) {
-            for (int j = 0; j < m; ++j) {
-                double s = 0.0;
-                for (int t = 0; t < n; ++t) s += (0.1 * fu[t * m + i]) * fu[t * m + j];
-                Puu[i * m + j] = s;
+            __syncthreads();
+            const int g = lane / REGU_BASE, c = lane % REGU_BASE;     // trajectory g, c + 1 rounds
+            int t = 1;
+            double mq = 0.0;
+            if (g < nsrc) {
+                double L[NL];
+                const double* const q = lds + g * 2 * NL;
+                ILQR_UNROLL
+                for (int e = 0; e < NL; ++e) L[e] = q[e];
+                double pw = 1.0;
+#pragma unroll 1
+                for (int i = 0; i <= c; ++i) {
+                    ILQR_UNROLL
+                    for (int e = 0; e < NL; ++e) L[e] += pw * q[NL + e];
+                    pw *= 2.0;
+                }
+                t = has_negative_eig_packed<w, UF>(L, mq);
             }
-            for (int j = 0; j < n; ++j) {
-                double s = 0.0;
-                for (int t = 0; t < n; ++t) s += (0.1 * fu[t * m + i]) * fx[t * n + j];
-                Pux[i * n + j] = s;
+            res[lane * 2] = (double)t;
+            res[lane * 2 + 1] = mq;
+            __syncthreads();
+            if (src) {
+                int cstar = -1, tt = 1;
+                double mqs = maxq;
+#pragma unroll 1
+                for (int c2 = 0; c2 < REGU_BASE; ++c2)
+                    if (cstar < 0) {
+                        tt = (int)res[(rank * REGU_BASE + c2) * 2];
+                        const double q2 = res[(rank * REGU_BASE + c2) * 2 + 1];
+                        mqs = (q2 > mqs) ? q2 : mqs;
+                        if (tt != 1) cstar = c2;
+                    }
+                maxq = mqs;
+                r = (cstar >= 0) ? cstar + 1 : REGU_BASE;
+                double PL[NL];
+                TR::regu_p(aux, PL);
+                double pw = 1.0;
+#pragma unroll 1
+                for (int i = 0; i < r; ++i) {
+                    ILQR_UNROLL
+                    for (int e = 0; e < NL; ++e) QL[e] += pw * PL[e];
+                    pw *= 2.0;
+                }
+                if (cstar >= 0) ok = ok && (tt >= 0);
+                else stuck_here = true;
+                need = false;
             }
+            pend &= ~__ballot(src);
+        }
+    } else {
+        // ---- big plants: rounds 1..REGU_BASE lane by lane
+        if (need) {
+            double PL[NL];
+            TR::regu_p(aux, PL);
+            double pw = 1.0;
+            while (need && r < REGU_BASE) {
+                for (int e = 0; e < NL; ++e) QL[e] += pw * PL[e];
+                pw *= 2.0;
+                r += 1;
+                double L[NL];
+                for (int e = 0; e < NL; ++e) L[e] = QL[e];
+                const int neg = has_negative_eig_packed<w, UF>(L, maxq);
+                ok = ok && (neg >= 0);
+                need = (neg == 1);
+            }
+            stuck_here = need;
         }
     }
-    double pw = 1.0;
-    while (need && r < REGU_LOCKSTEP) {
-        for (int e = 0; e < NQ; ++e) QQ[e] += pw * PP[e];
-        pw *= 2.0;
-        r += 1;
-        neg = has_negative_eig<n, m>(Qxx, Qux, Quu, maxq);
-        ok = ok && (neg >= 0);
-        need = (neg == 1);
-    }
 
-    // ---- lanes still failing: the wavefront scans r = REGU_LOCKSTEP+1, +2, ... for them, 64 at a time
-    unsigned long long stuck = __ballot(need);
-    const int lane = threadIdx.x & 63;
+    // ---- stuck scan: rounds REGU_BASE + 1, + 2, ... of one trajectory, 64 at a time
+    unsigned long long stuck = __ballot(stuck_here);
     while (stuck) {
         const int src = __ffsll((long long)stuck) - 1;
         stuck &= stuck - 1;
         __syncthreads();
-        if (lane == src)
-            for (int e = 0; e < NQ; ++e) {
-                lds[e] = QQ[e];
-                lds[NQ + e] = PP[e];
+        if (lane == src) {
+            double PL[NL];
+            TR::regu_p(aux, PL);
+            for (int e = 0; e < NL; ++e) {
+                lds[e] = QL[e];
+                lds[NL + e] = PL[e];
             }
+        }
         __syncthreads();
-        for (int base = REGU_LOCKSTEP + 1;; base += 64) {
+        for (int base = REGU_BASE + 1;; base += 64) {
             const int rc = base + lane;
             const double coef = ldexp(1.0, rc) - ldexp(1.0, REGU_EXACT);
-            double W[NQ];
-            for (int e = 0; e < NQ; ++e) W[e] = regu_entry(lds[e], lds[NQ + e], rc, coef);
+            double L[NL];
+            ILQR_UNROLL
+            for (int e = 0; e < NL; ++e) L[e] = lds[e];
+            double pw = (double)(1 << REGU_BASE);
+#pragma unroll 1
+            for (int i = REGU_BASE; i < REGU_EXACT; ++i) {
+                if (i < rc) {
+                    ILQR_UNROLL
+                    for (int e = 0; e < NL; ++e) L[e] += pw * lds[NL + e];
+                }
+                pw *= 2.0;
+            }
+            if (rc > REGU_EXACT) {
+                ILQR_UNROLL
+                for (int e = 0; e < NL; ++e) L[e] = __dadd_rn(L[e], __dmul_rn(coef, lds[NL + e]));
+            }
             double mq = 0.0;
-            const int t = has_negative_eig<n, m>(W, W + n * n, W + n * n + m * n, mq);
+            const int t = has_negative_eig_packed<w, UF>(L, mq);
             const unsigned long long stops = __ballot(t != 1);
             if (stops) {
                 const int win = __ffsll((long long)stops) - 1;
-                __syncthreads();
                 if (lane == win) {
-                    for (int e = 0; e < NQ; ++e) lds[e] = regu_entry(lds[e], lds[NQ + e], rc, coef);
-                    lds[2 * NQ] = (double)t;
-                    lds[2 * NQ + 1] = (double)rc;
-                    lds[2 * NQ + 2] = mq;
+                    res[0] = (double)t;
+                    res[1] = mq;
                 }
                 __syncthreads();
                 if (lane == src) {
-                    for (int e = 0; e < NQ; ++e) QQ[e] = lds[e];
-                    ok = ok && (lds[2 * NQ] >= 0.0);
-                    r = (int)lds[2 * NQ + 1];
-                    maxq = (lds[2 * NQ + 2] > maxq) ? lds[2 * NQ + 2] : maxq;
+                    const int rw = base + win;
+                    const double cw = ldexp(1.0, rw) - ldexp(1.0, REGU_EXACT);
+                    double PL[NL];
+                    TR::regu_p(aux, PL);
+                    double pw2 = (double)(1 << REGU_BASE);
+#pragma unroll 1
+                    for (int i = REGU_BASE; i < REGU_EXACT; ++i) {
+                        if (i < rw) {
+                            ILQR_UNROLL
+                            for (int e = 0; e < NL; ++e) QL[e] += pw2 * PL[e];
+                        }
+                        pw2 *= 2.0;
+                    }
+                    if (rw > REGU_EXACT) {
+                        ILQR_UNROLL
+                        for (int e = 0; e < NL; ++e) QL[e] = __dadd_rn(QL[e], __dmul_rn(cw, PL[e]));
+                    }
+                    ok = ok && (res[0] >= 0.0);
+                    r = rw;
+                    maxq = (res[1] > maxq) ? res[1] : maxq;
                 }
                 break;
             }
@@ -365,52 +538,74 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
     regu_rounds += r;
     if (!ok) return false;
 
-    // gains: d = -Quu^-1 Qu, K = -Quu^-1 Qux
-    double Qinv[m * m];
+    // ---- gains (iLQRController.py:125-129): d = -Quu^-1 Qu, K = -Quu^-1 Qux
+    double Quu[m * m], Qinv[m * m];
+    ILQR_UNROLL
+    for (int a = 0; a < m; ++a)
+        ILQR_UNROLL
+        for (int b = 0; b < m; ++b) Quu[a * m + b] = QL[sym(n + a, n + b)];
     if (!inv_small<m>(Quu, Qinv)) return false;
-    for (int i = 0; i < m; ++i) {
+    ILQR_UNROLL
+    for (int a = 0; a < m; ++a) {
         double s = 0.0;
-        for (int t = 0; t < m; ++t) s += (-Qinv[i * m + t]) * Qu[t];
-        dk[i] = s;
+        ILQR_UNROLL
+        for (int b = 0; b < m; ++b) s += (-Qinv[a * m + b]) * Qu[b];
+        dk[a] = s;
+        ILQR_UNROLL
         for (int j = 0; j < n; ++j) {
             double rr = 0.0;
-            for (int t = 0; t < m; ++t) rr += (-Qinv[i * m + t]) * Qux[t * n + j];
-            Kk[i * n + j] = rr;
+            ILQR_UNROLL
+            for (int b = 0; b < m; ++b) rr += (-Qinv[a * m + b]) * QL[tri(n + b, j)];
+            Kk[a * n + j] = rr;
         }
     }
 
-    // V_xx = Q_xx + K'Q_uu K + K'Q_ux + Q_ux'K ; V_x = Q_x + K'Q_uu d + K'Q_u + Q_ux'd
+    // ---- V_xx = Q_xx + K'Q_uu K + K'Q_ux + Q_ux'K ; V_x = Q_x + K'Q_uu d + K'Q_u + Q_ux'd  (:131-134)
     double KtQuu[n * m];
+    ILQR_UNROLL
     for (int i = 0; i < n; ++i)
-        for (int j = 0; j < m; ++j) {
+        ILQR_UNROLL
+        for (int b = 0; b < m; ++b) {
             double s = 0.0;
-            for (int t = 0; t < m; ++t) s += Kk[t * n + i] * Quu[t * m + j];
-            KtQuu[i * m + j] = s;
+            ILQR_UNROLL
+            for (int a = 0; a < m; ++a) s += Kk[a * n + i] * Quu[a * m + b];
+            KtQuu[i * m + b] = s;
         }
+    ILQR_UNROLL
     for (int i = 0; i < n; ++i) {
-        for (int j = 0; j < n; ++j) {
+        ILQR_UNROLL
+        for (int j = 0; j <= i; ++j) {
             double t1 = 0.0, t2 = 0.0, t3 = 0.0;
-            for (int t = 0; t < m; ++t) t1 += KtQuu[i * m + t] * Kk[t * n + j];
-            for (int t = 0; t < m; ++t) t2 += Kk[t * n + i] * Qux[t * n + j];
-            for (int t = 0; t < m; ++t) t3 += Qux[t * n + i] * Kk[t * n + j];
-            Vxx[i * n + j] = ((Qxx[i * n + j] + t1) + t2) + t3;
+            ILQR_UNROLL
+            for (int a = 0; a < m; ++a) t1 += KtQuu[i * m + a] * Kk[a * n + j];
+            ILQR_UNROLL
+            for (int a = 0; a < m; ++a) t2 += Kk[a * n + i] * QL[tri(n + a, j)];
+            ILQR_UNROLL
+            for (int a = 0; a < m; ++a) t3 += QL[tri(n + a, i)] * Kk[a * n + j];
+            VL[tri(i, j)] = ((QL[tri(i, j)] + t1) + t2) + t3;
         }
-        double a = 0.0, b = 0.0, c = 0.0;
-        for (int t = 0; t < m; ++t) a += KtQuu[i * m + t] * dk[t];
-        for (int t = 0; t < m; ++t) b += Kk[t * n + i] * Qu[t];
-        for (int t = 0; t < m; ++t) c += Qux[t * n + i] * dk[t];
-        Vx[i] = ((Qx[i] + a) + b) + c;
+        double a1 = 0.0, b1 = 0.0, c1 = 0.0;
+        ILQR_UNROLL
+        for (int a = 0; a < m; ++a) a1 += KtQuu[i * m + a] * dk[a];
+        ILQR_UNROLL
+        for (int a = 0; a < m; ++a) b1 += Kk[a * n + i] * Qu[a];
+        ILQR_UNROLL
+        for (int a = 0; a < m; ++a) c1 += QL[tri(n + a, i)] * dk[a];
+        Vx[i] = ((Qx[i] + a1) + b1) + c1;
     }
 
-    // expected cost reduction: -Q_u'd - 0.5 d'(Q_uu' d)
-    double a = 0.0, b = 0.0;
-    for (int i = 0; i < m; ++i) a += (-Qu[i]) * dk[i];
-    for (int i = 0; i < m; ++i) {
+    // ---- expected cost reduction (:136-137): -Q_u'd - 0.5 d'(Q_uu' d)
+    double ea = 0.0, eb = 0.0;
+    ILQR_UNROLL
+    for (int a = 0; a < m; ++a) ea += (-Qu[a]) * dk[a];
+    ILQR_UNROLL
+    for (int a = 0; a < m; ++a) {
         double s = 0.0;
-        for (int t = 0; t < m; ++t) s += Quu[t * m + i] * dk[t];
-        b += (0.5 * dk[i]) * s;
+        ILQR_UNROLL
+        for (int b = 0; b < m; ++b) s += Quu[b * m + a] * dk[b];
+        eb += (0.5 * dk[a]) * s;
     }
-    redu += a - b;
+    redu += ea - eb;
     return true;
 }
 
@@ -426,17 +621,18 @@ __device__ inline bool backward_pass(const double* par, const CLane& X, const CL
                                      int S, double& deltaJ, double& dmax, int& regu_rounds, int& regu_stages,
                                      double& maxq, bool active, double* lds)
 {
+    using TR = typename TermsOf<M>::type;
     constexpr int n = M::NDX, m = M::NU, nx = M::NX;
-    double Vx[n], Vxx[n * n], xk[nx], uk[m], dk[m], Kk[m * n];
+    double Vx[n], VL[n * (n + 1) / 2], xk[nx], uk[m], dk[m], Kk[m * n];
     load_vec<nx>(X, S, xk);
-    M::final(par, xk, Vx, Vxx);
+    TR::final_sym(par, xk, Vx, VL);
     double redu = 0.0, best = -INFINITY;
     bool anynan = false, ok = true;
     for (int k = S - 1; k >= 0; --k) {
         load_vec<nx>(X, k, xk);
         load_vec<m>(U, k, uk);
         const bool alive = active && ok;
-        const bool good = backward_stage<M>(par, xk, uk, Vx, Vxx, dk, Kk, redu, regu_rounds, regu_stages, maxq, alive,
+        const bool good = backward_stage<M>(par, xk, uk, Vx, VL, dk, Kk, redu, regu_rounds, regu_stages, maxq, alive,
                                             lds);
         ok = ok && good;
         if (alive && good) {

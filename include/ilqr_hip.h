@@ -58,9 +58,13 @@ typedef struct {
     int32_t flags;        /* ILQR_FLAG_* */
 } ilqr_problem;
 
+/* Line-search evaluation schedule (the result does not depend on it):
+ * default: candidate 1 (alpha = 1) for every trajectory, candidates 2 and 3 one launch each for those
+ * still searching, then all remaining candidates side by side, one lane each, first stopping one wins. */
 enum {
     ILQR_FLAG_NONE = 0,
-    ILQR_FLAG_PARALLEL_LS = 1 /* evaluate the backtracking alphas of a failed first step side by side */
+    ILQR_FLAG_PARALLEL_LS = 1,   /* side by side right after alpha = 1 was rejected */
+    ILQR_FLAG_LS_SEQUENTIAL = 2  /* never side by side: one launch per candidate */
 };
 
 /* per-trajectory results; any pointer may be NULL.  Arrays are [B] (index b),
@@ -95,7 +99,8 @@ size_t ilqr_workspace_bytes(const ilqr_problem *p);
  *   x0 [nx][stride]        in
  *   u  [N-1][nu][stride]   in: initial controls; out: optimised controls (in place, like :72)
  *   x  [N][nx][stride]     out: optimised states (:71, :84)
- * `stream` is a hipStream_t (NULL = default stream).  The call only enqueues work. */
+ * `stream` is a hipStream_t (NULL = default stream).  The call blocks: it waits on `stream`
+ * a few times per solver iteration to read back how many trajectories are still running. */
 int ilqr_solve_batch(const ilqr_problem *p, const double *x0, double *u, double *x, const ilqr_outputs *out,
                      void *workspace, size_t workspace_bytes, void *stream);
 

@@ -90,23 +90,26 @@ static void full_hessian(const double *Qxx, const double *Qux, const double *Quu
 
 /* Stand-in for `np.any(np.linalg.eigvals(Q) < 0)` (iLQRController.py:110).
  * Right-looking LDL^T on the lower triangle, natural order, no pivoting.
- *   pivot < -tol*|Q_jj|                  -> a negative eigenvalue exists
- *   |pivot| <= tol*|Q_jj|, column ~ 0    -> zero eigenvalue, deflate, go on
- *   |pivot| <= tol*|Q_jj|, column != 0   -> indefinite 2x2 minor -> negative
- * tol = ILQR_PIVOT_TOL: a pivot that cancelled to 1e-13 of its diagonal entry is
- * rounding noise.  (With tol = 0 a Q dominated by regu*[fx fu]'[fx fu], which is
- * rank deficient, keeps the same noise sign through every further doubling.)
+ *   pivot < -tol*acc_j                  -> a negative eigenvalue exists
+ *   |pivot| <= tol*acc_j, column ~ 0    -> zero eigenvalue, deflate, go on
+ *   |pivot| <= tol*acc_j, column != 0   -> indefinite 2x2 minor -> negative
+ * acc_j = |Q_jj| + sum_k |l_jk^2 d_k| is the size of the terms pivot j is the difference
+ * of, tol = ILQR_PIVOT_TOL: a pivot that cancelled to 1e-13 of them is rounding noise.
+ * (With tol = 0 a Q dominated by regu*[fx fu]'[fx fu], which is rank deficient, keeps
+ * the same noise sign through every further doubling of regu.)
  * Returns 1 = negative eigenvalue, 0 = none, -1 = Q not finite (NumPy raises
  * LinAlgError there). `W` is scratch of w*w doubles. */
 int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W)
 {
+    double acc[ILQR_MAX_NDX + ILQR_MAX_NU];   /* |Q_jj| + sum of |l_jk^2 d_k|: the magnitudes pivot j is a difference of */
     for (int i = 0; i < w * w; ++i) {
         if (!isfinite(Q[i])) return -1;
         W[i] = Q[i];
     }
+    for (int j = 0; j < w; ++j) acc[j] = fabs(Q[j * w + j]);
     for (int j = 0; j < w; ++j) {
         double p = W[j * w + j];
-        double thr = ILQR_PIVOT_TOL * fabs(Q[j * w + j]);
+        double thr = ILQR_PIVOT_TOL * acc[j];
         if (p < -thr) return 1;
         if (p <= thr) {
             /* (numerically) zero pivot: a positive semi-definite matrix then has a
@@ -121,6 +124,7 @@ int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W)
         for (int i = j + 1; i < w; ++i) {
             double lij = W[i * w + j] * pinv;
             for (int k = j + 1; k <= i; ++k) W[i * w + k] -= lij * W[k * w + j];
+            acc[i] += fabs(lij * W[i * w + j]);
         }
     }
     return 0;

@@ -19,11 +19,11 @@ def torch_gpu():
     return torch
 
 
-def _solve(g_or_cfg, x0, u0, trace=64):
+def _solve(g_or_cfg, x0, u0, trace=64, flags=0):
     from ilqr_amd.batch import BatchSolver
     c = g_or_cfg
     s = BatchSolver(MID[str(c["model"])], c["par"], int(c["N"]), int(c["max_iter"]), int(c["max_ls"]),
-                    float(c["d_tol"]), trace_len=trace)
+                    float(c["d_tol"]), trace_len=trace, flags=flags)
     r = s.solve(x0, u0)
     cp = lambda t: t.cpu().numpy()
     return dict(x=cp(r.x), u=cp(r.u), J=cp(r.J), J0=cp(r.J0), iters=cp(r.iters), status=cp(r.status),
@@ -188,6 +188,20 @@ def test_same_batch_is_bitwise_reproducible_and_shards_agree(torch_gpu, oracle):
         whole = a[k]
         parts = np.concatenate([h1[k], h2[k]])
         assert np.array_equal(whole, parts, equal_nan=True) if whole.dtype.kind == "f" else np.array_equal(whole, parts), k
+
+
+@pytest.mark.parametrize("name", ["car_bigu", "car_maxls2", "car_box256", "acrobot_N40", "quad_quat_N30"])
+def test_line_search_schedule_does_not_change_results(torch_gpu, name):
+    """Candidates evaluated one launch per alpha, side by side, or mixed: bit-identical results and counts."""
+    from ilqr_amd import _lib
+    g = load_golden(name)
+    base = _solve(g, g["x0"], g["u_init"], flags=_lib.FLAG_LS_SEQUENTIAL)
+    assert (base["ls"] > 1).any()
+    for flags in (0, _lib.FLAG_PARALLEL_LS):
+        r = _solve(g, g["x0"], g["u_init"], flags=flags)
+        for k in ("x", "u", "J", "iters", "status", "regu", "ls", "acc", "ls_total"):
+            eq = np.array_equal(base[k], r[k], equal_nan=True) if base[k].dtype.kind == "f" else np.array_equal(base[k], r[k])
+            assert eq, (name, flags, k)
 
 
 def test_drop_in_single_trajectory_api(torch_gpu):

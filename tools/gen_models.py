@@ -107,13 +107,17 @@ def _count_ops(exprs):
     return c
 
 
-def emit_function(name, inputs, outputs, doc):
+def emit_function(name, inputs, outputs, doc, pre=None):
     """inputs: list of (cname, [symbols]); outputs: list of (cname, sympy Matrix or list).
-    Dense row-major outputs; structural zeros are written as 0.0."""
+    Dense row-major outputs; structural zeros are written as 0.0.
+    pre: optional list of (symbol, expression) evaluated first, in order, as named temporaries."""
     flat = []
     for _, M in outputs:
         M = sp.Matrix(M)
         flat.extend(list(M))          # row-major
+    pre = pre or []
+    npre = len(pre)
+    flat = [e for _, e in pre] + flat
     t0 = time.time()
     repl, red = sp.cse(flat, symbols=sp.numbered_symbols("t"), optimizations="basic", order="none")
     lines = []
@@ -134,6 +138,9 @@ def emit_function(name, inputs, outputs, doc):
             lines.append(f"    (void){n};")
     for t, e in repl:
         lines.append(f"    const double {t} = {_P.doprint(e.xreplace(sub))};")
+    for k in range(npre):
+        lines.append(f"    const double {pre[k][0]} = {_P.doprint(red[k].xreplace(sub))};")
+    red = red[npre:]
     k = 0
     for n, M in outputs:
         M = sp.Matrix(M)
@@ -192,6 +199,53 @@ def gen_car():
     out += s
     s, ops["final"] = emit_function("car_gen_final", ins[:2], [("V_x", lfx), ("V_xx", lfx.jacobian(xs))],
                                     "final-cost derivatives (car.py:46-52)")
+    out += s
+    # ---- backward-stage terms on symmetric (packed lower triangle) storage, sparsity folded in by SymPy
+    n, m = 5, 2
+    w = n + m
+    Vx = sp.symbols("Vx0:5", real=True)
+    VLs = sp.symbols("VL0:15", real=True)
+    V = sp.zeros(n, n)
+    for i in range(n):
+        for j in range(i + 1):
+            V[i, j] = V[j, i] = VLs[i * (i + 1) // 2 + j]
+    fx = f.jacobian(xs)
+    fu = f.jacobian(us)
+    # name the six state-dependent entries of f_x so that products are formed from them, not re-derived
+    fa_pos = [(0, 2), (0, 3), (1, 2), (1, 3), (2, 3), (2, 4)]
+    fa = sp.symbols("fa0:6", real=True)
+    fxs = sp.Matrix(fx)
+    for k, (i, j) in enumerate(fa_pos):
+        fxs[i, j] = fa[k]
+    assert all(fxs[i, j].is_number or fxs[i, j] in fa for i in range(n) for j in range(n))
+    Wm = V * fxs                                  # V f_x
+    Ws = sp.Matrix(n, n, lambda i, j: sp.Symbol(f"W{i}{j}", real=True))
+    lxx = lx.jacobian(xs)
+    Qxx = lxx + fxs.T * Ws
+    Qux = lu.jacobian(xs) + fu.T * Ws
+    Quu = lu.jacobian(us) + fu.T * V * fu
+    Qx_e = lx.T + fxs.T * sp.Matrix(Vx)
+    Qu_e = lu.T + fu.T * sp.Matrix(Vx)
+    full = sp.zeros(w, w)
+    full[:n, :n] = Qxx
+    full[n:, :n] = Qux
+    full[n:, n:] = Quu
+    QL = [full[i, j] for i in range(w) for j in range(i + 1)]
+    # substitute: fa_k and W_ij are emitted as temporaries first
+    pre = [(fa[k], fx[i, j]) for k, (i, j) in enumerate(fa_pos)] + \
+          [(Ws[i, j], Wm[i, j]) for i in range(n) for j in range(n)]
+    s, ops["backward_terms"] = emit_function(
+        "car_gen_backward_terms", [("p", ps), ("x", xs), ("u", us), ("Vx", Vx), ("VL", VLs)],
+        [("Qx", Qx_e), ("Qu", Qu_e), ("QL", QL), ("fa", list(fa))],
+        "Q-function terms of one backward stage (control/models/model.py:45-53) for symmetric V_xx: "
+        "Qx[5], Qu[2], QL[28] = packed lower triangle of [[Qxx, Qux'], [Qux, Quu]], fa[6] = the state-dependent "
+        "entries (0,2) (0,3) (1,2) (1,3) (2,3) (2,4) of f_x", pre=pre)
+    out += s
+    Fm = sp.Matrix(n, w, lambda i, j: fxs[i, j] if j < n else fu[i, j - n])
+    P = sp.Matrix(w, w, lambda i, j: sum((sp.Float(0.1) * Fm[t, i]) * Fm[t, j] for t in range(n)))
+    s, ops["regu_p"] = emit_function(
+        "car_gen_regu_p", [("fa", fa)], [("PL", [P[i, j] for i in range(w) for j in range(i + 1)])],
+        "packed lower triangle of (0.1 [fx fu])'[fx fu], the regularisation update of iLQRController.py:111-113 at regu = 0.1")
     out += s
     return out, ops
 
