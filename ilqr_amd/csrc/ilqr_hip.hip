@@ -135,28 +135,31 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
     if (p->stride < p->B) return fail(ILQR_E_BADARG, "stride must be >= B");
     if (!p->params) return fail(ILQR_E_BADARG, "params is NULL");
     if (p->max_iter < 0 || p->max_ls < 0 || p->trace_len < 0) return fail(ILQR_E_BADARG, "negative count");
+    if ((p->flags & ILQR_FLAG_LS_SEQUENTIAL) && p->max_ls > 60)
+        return fail(ILQR_E_BADARG, "ILQR_FLAG_LS_SEQUENTIAL supports max_ls <= 60");
     return ILQR_OK;
 }
 
 struct WsLayout {
-    size_t XA, XB, UA, UB, D, K, dJ, J0, J, dmax, maxq, iters, status, regu_rounds, regu_stages, ls_total, idA, idB,
-        ls_slot, ls_dest, bt, bt2, cnt, total;
+    size_t TA, TB, G, dJ, J0, J, dmax, maxq, iters, status, regu_rounds, regu_stages, ls_total, idA, idB,
+        ls_slot, ls_dest, bt, bt2, win_ls, win_J, cnt, total;
 };
 WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
 {
     const size_t cap = (size_t)p->stride, S = (size_t)p->N - 1, N = (size_t)p->N;
+    const size_t RT = (size_t)(d.nx + d.nu + 7) / 8 * 8, RG = (size_t)(d.nu + d.nu * d.ndx + 7) / 8 * 8;   // Rec<M>
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     WsLayout w;
-    w.XA = take(N * d.nx * cap * 8); w.XB = take(N * d.nx * cap * 8);
-    w.UA = take(S * d.nu * cap * 8); w.UB = take(S * d.nu * cap * 8);
-    w.D = take(S * d.nu * cap * 8);  w.K = take(S * d.nu * d.ndx * cap * 8);
+    w.TA = take(N * RT * cap * 8); w.TB = take(N * RT * cap * 8);
+    w.G = take(S * RG * cap * 8);
     w.dJ = take(cap * 8);
     w.J0 = take(cap * 8); w.J = take(cap * 8); w.dmax = take(cap * 8); w.maxq = take(cap * 8);
     w.iters = take(cap * 4); w.status = take(cap * 4); w.regu_rounds = take(cap * 4); w.regu_stages = take(cap * 4);
     w.ls_total = take(cap * 4);
     w.idA = take(cap * 4); w.idB = take(cap * 4); w.ls_slot = take(cap * 4); w.ls_dest = take(cap * 4);
     w.bt = take(cap * 4); w.bt2 = take(cap * 4);
+    w.win_ls = take(cap * 4); w.win_J = take(cap * 8);
     w.cnt = take(64 * 4);
     w.total = off;
     return w;
@@ -165,11 +168,12 @@ WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
 inline unsigned blocks_for(long n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 // run_ilqr for the whole batch: see solve_pipeline.hpp.  Blocks the calling thread on `stream`
-// twice per solver iteration to size the next launch (a 12-byte read-back).
+// twice per solver iteration to size the next launches (a few bytes read back).
 template <class M>
 int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, const ilqr_outputs* out, char* ws,
                  const WsLayout& w, hipStream_t st)
 {
+    static_assert(Rec<M>::RT == (M::NX + M::NU + 7) / 8 * 8 && Rec<M>::RG == (M::NU + M::NU * M::NDX + 7) / 8 * 8, "");
     Pipe a;
     memset(&a, 0, sizeof(a));
     a.N = p->N; a.max_iter = p->max_iter; a.max_ls = p->max_ls; a.trace_len = p->trace_len; a.flags = p->flags;
@@ -187,10 +191,11 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     a.regu_stages = o.regu_stages ? o.regu_stages : (int32_t*)(ws + w.regu_stages);
     a.ls_total = o.ls_total ? o.ls_total : (int32_t*)(ws + w.ls_total);
     a.tr_ls = o.ls_evals; a.tr_acc = o.accepted; a.tr_J = o.J_trace; a.tr_dJ = o.deltaJ_trace;
-    a.XA = (double*)(ws + w.XA); a.XB = (double*)(ws + w.XB); a.UA = (double*)(ws + w.UA); a.UB = (double*)(ws + w.UB);
-    a.D = (double*)(ws + w.D); a.K = (double*)(ws + w.K); a.dJ = (double*)(ws + w.dJ);
+    a.TA = (double*)(ws + w.TA); a.TB = (double*)(ws + w.TB); a.G = (double*)(ws + w.G); a.dJ = (double*)(ws + w.dJ);
     a.idA = (int32_t*)(ws + w.idA); a.idB = (int32_t*)(ws + w.idB);
-    a.ls_slot = (int32_t*)(ws + w.ls_slot); a.ls_dest = (int32_t*)(ws + w.ls_dest); a.bt = (int32_t*)(ws + w.bt); a.bt2 = (int32_t*)(ws + w.bt2);
+    a.ls_slot = (int32_t*)(ws + w.ls_slot); a.ls_dest = (int32_t*)(ws + w.ls_dest);
+    a.bt = (int32_t*)(ws + w.bt); a.bt2 = (int32_t*)(ws + w.bt2);
+    a.win_ls = (int32_t*)(ws + w.win_ls); a.win_J = (double*)(ws + w.win_J);
     a.cnt = (int32_t*)(ws + w.cnt);
 
     hipLaunchKernelGGL(pipe_init_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
@@ -202,10 +207,11 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
         HIP_TRY(hipGetLastError());
         return ILQR_OK;
     }
-    // line-search schedule: evaluation 1 for everybody, evaluations 2..seq_levels one launch each over the
-    // compacted list of trajectories still searching, then every remaining candidate side by side
-    const int seq_levels = (a.flags & ILQR_FLAG_LS_SEQUENTIAL) ? a.max_ls
-                         : (a.flags & ILQR_FLAG_PARALLEL_LS) ? 1 : 3;
+    // Line-search schedule after evaluation 1 (all three give bit-identical results):
+    //   default                  evaluations 2..5 four lanes per trajectory, then 6.. sixteen at a time, commit
+    //   ILQR_FLAG_PARALLEL_LS    evaluations 2.. sixteen at a time, commit
+    //   ILQR_FLAG_LS_SEQUENTIAL  one launch per evaluation over the compacted list of those still searching
+    constexpr int GA = 4, GB = 16;
     int32_t h[4];
     long count = a.B;
     for (int iter = 1; iter <= a.max_iter && count > 0; ++iter) {
@@ -223,31 +229,42 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
             HIP_TRY(hipMemcpyAsync(h + 2, a.cnt + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             long bound = h[2];                    // trajectories whose first candidate was rejected
-            int32_t *lin = a.bt, *lout = a.bt2;
-            int ls = 2;
-            double alpha = 0.5;
-            for (; bound > 0 && ls <= a.max_ls && (ls <= seq_levels || a.max_ls - ls + 1 > 64); ++ls, alpha *= 0.5) {
-                hipLaunchKernelGGL(pipe_forward_level_kernel<M>, dim3(blocks_for(bound, PIPE_WG)), dim3(PIPE_WG), 0, st,
-                                   a, lin, a.cnt + ls, lout, a.cnt + ls + 1, ls, alpha);
-                HIP_TRY(hipGetLastError());
-                int32_t* t = lin; lin = lout; lout = t;
-                if (ls == seq_levels || (ls % 4) == 0) {     // tighten the bound now and then
-                    HIP_TRY(hipMemcpyAsync(h + 3, a.cnt + ls + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-                    HIP_TRY(hipStreamSynchronize(st));
-                    bound = h[3];
+            if (bound > 0 && a.max_ls >= 2 && (a.flags & ILQR_FLAG_LS_SEQUENTIAL)) {
+                int32_t *lin = a.bt, *lout = a.bt2;
+                double alpha = 0.5;
+                for (int ls = 2; bound > 0 && ls <= a.max_ls; ++ls, alpha *= 0.5) {
+                    hipLaunchKernelGGL(pipe_forward_level_kernel<M>, dim3(blocks_for(bound, PIPE_WG)), dim3(PIPE_WG), 0,
+                                       st, a, lin, a.cnt + ls, lout, a.cnt + ls + 1, ls, alpha);
+                    HIP_TRY(hipGetLastError());
+                    int32_t* t = lin; lin = lout; lout = t;
+                    if ((ls % 4) == 0) {     // tighten the bound now and then
+                        HIP_TRY(hipMemcpyAsync(h + 3, a.cnt + ls + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                        HIP_TRY(hipStreamSynchronize(st));
+                        bound = h[3];
+                    }
                 }
-            }
-            if (bound > 0 && ls <= a.max_ls) {
-                const int per_wave = 64 / (a.max_ls - ls + 1);
-                hipLaunchKernelGGL(pipe_backtrack_parallel_kernel<M>, dim3(blocks_for(bound, per_wave)), dim3(PIPE_WG),
-                                   0, st, a, lin, a.cnt + ls, ls);
+            } else if (bound > 0 && a.max_ls >= 2) {
+                const int32_t* lin = a.bt;
+                const int32_t* nin = a.cnt + 2;
+                int first = 2;
+                if (!(a.flags & ILQR_FLAG_PARALLEL_LS)) {
+                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GA, false>), dim3(blocks_for(bound, 64 / GA)),
+                                       dim3(PIPE_WG), 0, st, a, lin, nin, a.bt2, a.cnt + 3, first);
+                    HIP_TRY(hipGetLastError());
+                    lin = a.bt2; nin = a.cnt + 3; first += GA;
+                }
+                if (first <= a.max_ls) {
+                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GB, true>), dim3(blocks_for(bound, 64 / GB)),
+                                       dim3(PIPE_WG), 0, st, a, lin, nin, (int32_t*)nullptr, (int32_t*)nullptr, first);
+                    HIP_TRY(hipGetLastError());
+                }
+                hipLaunchKernelGGL(pipe_commit_kernel<M>, dim3(blocks_for(bound, PIPE_WG)), dim3(PIPE_WG), 0, st, a,
+                                   a.bt, a.cnt + 2);
                 HIP_TRY(hipGetLastError());
             }
         }
         // the buffer the candidates were written to becomes the current one
-        double* t;
-        t = a.XA; a.XA = a.XB; a.XB = t;
-        t = a.UA; a.UA = a.UB; a.UB = t;
+        double* t = a.TA; a.TA = a.TB; a.TB = t;
         int32_t* ti = a.idA; a.idA = a.idB; a.idB = ti;
         count = next;
     }

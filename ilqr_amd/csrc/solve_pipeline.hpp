@@ -10,18 +10,28 @@
 //
 //   init      rollout + cost of the initial guess            (:27-34)
 //   backward  Riccati sweep, exit tests, slot allocation      (:43-51, :98-123)
-//   forward1  first line-search candidate, alpha = 1          (:60-68, :87-96)
-//   level L   candidate number L (alpha = 0.5^(L-1)) for those still searching, one launch per level
-//   parallel  all remaining candidates side by side, first stopping one wins (:60-68)
+//   forward1  first line-search candidate, alpha = 1, written (:60-68, :87-96)
+//   group<4>  candidates 2..5 of the rejected ones side by side, cost only
+//   group<16> candidates 6.. of those still searching, 16 at a time, cost only
+//   commit    the candidate each backtracking search stopped at is written (:66-72)
 //
-// State of a running trajectory (x, u) lives in one of two slot-indexed
-// structure-of-arrays buffers; the forward pass, which has to write the new
-// trajectory anyway, writes it into the slot the trajectory will occupy in the
-// next iteration (slots are handed out densely with one wave-aggregated atomic
-// per wavefront), so every kernel reads and writes 64 consecutive doubles per
-// wave instruction although the set of running trajectories keeps shrinking.
-// A trajectory that finishes writes its result to the caller's buffers at its
-// own index.  Results per trajectory do not depend on the slot order.
+// State of a running trajectory (x, u) lives in one of two slot-indexed record
+// buffers (solver_device.hpp, Rec); the forward pass, which has to write the
+// new trajectory anyway, writes it into the slot the trajectory will occupy in
+// the next iteration (slots are handed out densely with one wave-aggregated
+// atomic per wavefront), so the big kernels read and write contiguous spans
+// although the set of running trajectories keeps shrinking.  A trajectory
+// that finishes writes its result to the caller's arrays at its own index.
+// Results per trajectory do not depend on the slot order.
+//
+// Line search.  The reference tries alpha = 1, 1/2, 1/4, ... one after the
+// other and stops at the first candidate that meets the Armijo test (or is
+// NaN, or is number max_ls).  Candidates do not depend on each other, so after
+// the first one the kernels evaluate several per trajectory in neighbouring
+// lanes (which share every load of the trajectory's records) and a ballot picks
+// the first one, in the reference's order, at which the sequential loop would
+// have stopped.  Only costs are computed there; `commit` re-runs the one
+// forward pass whose result is kept, one trajectory per lane.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -36,7 +46,7 @@ struct Pipe {
     // problem
     int N, max_iter, max_ls, trace_len, flags;
     double d_tol;
-    long B, cap;               // trajectories, slot capacity (= stride of every buffer)
+    long B, cap;               // trajectories, slot capacity (= stride of the caller's arrays)
     const double* par;
     // caller buffers (indexed by trajectory id)
     const double* x0;
@@ -50,10 +60,12 @@ struct Pipe {
     uint8_t* tr_acc;
     double *tr_J, *tr_dJ;
     // slot-indexed buffers
-    double *XA, *XB, *UA, *UB, *D, *K, *dJ;
+    double *TA, *TB, *G, *dJ;  // T records now / next iteration, G records, expected reduction
     int32_t *idA, *idB, *ls_slot, *ls_dest, *bt, *bt2;
-    int32_t* cnt;              // [0] slots handed out in B, [1] line-search entries, [1 + L] entries that go on
-                               // after evaluation number L (L = 1, 2, ...)
+    int32_t* win_ls;           // per line-search entry: evaluation number the search stopped at (< 0: not accepted)
+    double* win_J;             // ... and that candidate's cost
+    int32_t* cnt;              // [0] slots handed out in B, [1] line-search entries, [2] rejected at alpha = 1,
+                               // [3..] list lengths of the later stages
     int count;                 // running trajectories = used slots of buffer A
     int iter;                  // 1-based number of the iteration being run
 };
@@ -77,26 +89,42 @@ __device__ __forceinline__ int wave_append(bool pred, int32_t* counter)
 }
 
 template <class M>
-__device__ inline void copy_traj(const CLane& Xs, const CLane& Us, const Lane& Xd, const Lane& Ud, int N)
+__device__ __forceinline__ RecIn slot_T(const double* buf, long cap, int s)
 {
-    for (int i = 0; i < N * M::NX; ++i) Xd.st(i, Xs.ld(i));
-    for (int i = 0; i < (N - 1) * M::NU; ++i) Ud.st(i, Us.ld(i));
+    return RecIn{buf + (long)s * Rec<M>::RT, cap * Rec<M>::RT};
+}
+template <class M>
+__device__ __forceinline__ RecIn slot_G(const Pipe& a, int s)
+{
+    return RecIn{a.G + (long)s * Rec<M>::RG, a.cap * Rec<M>::RG};
+}
+template <class M>
+__device__ __forceinline__ Dest<M> caller_dest(const Pipe& a, int id)
+{
+    return Dest<M>{nullptr, 0, a.x + id, a.u + id, a.cap};
+}
+// Where a line-search candidate is written: the trajectory's slot in the next
+// iteration's buffer, or straight into the caller's arrays when this was its
+// last iteration.
+template <class M>
+__device__ __forceinline__ Dest<M> make_dest(const Pipe& a, int dest, int id)
+{
+    return dest >= 0 ? Dest<M>{a.TB + (long)dest * Rec<M>::RT, a.cap * Rec<M>::RT, nullptr, nullptr, 0}
+                     : caller_dest<M>(a, id);
 }
 
 // ---------------------------------------------------------------- init
 template <class M>
 __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
 {
-    constexpr int nx = M::NX, m = M::NU;
+    constexpr int nx = M::NX;
     const long b = (long)blockIdx.x * PIPE_WG + threadIdx.x;
     if (b >= a.B) return;
     const int S = a.N - 1;
     double xs[nx];
     for (int i = 0; i < nx; ++i) xs[i] = a.x0[(long)i * a.cap + b];
-    const Lane UA{a.UA + b, a.cap};
-    const CLane Uin{a.u + b, a.cap};
-    for (int i = 0; i < S * m; ++i) UA.st(i, Uin.ld(i));
-    const double J = rollout_cost<M>(a.par, xs, Uin, Lane{a.XA + b, a.cap}, S);     // iLQRController.py:27-34
+    const Dest<M> out{a.TA + b * Rec<M>::RT, a.cap * Rec<M>::RT, nullptr, nullptr, 0};
+    const double J = rollout_cost_rec<M>(a.par, xs, CLane{a.u + b, a.cap}, out, S);     // iLQRController.py:27-34
     a.idA[b] = (int)b;
     a.J0[b] = J;
     a.J[b] = J;
@@ -110,15 +138,13 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
 }
 
 // The loop test of :43 failed before the first iteration (d_tol is +inf/NaN or
-// max_iter == 0): the initial rollout is the result.
+// max_iter == 0): the initial rollout is the result (u is left as it came).
 template <class M>
 __global__ __launch_bounds__(PIPE_WG) void pipe_finish_all_kernel(Pipe a, int status)
 {
     const long b = (long)blockIdx.x * PIPE_WG + threadIdx.x;
     if (b >= a.B) return;
-    const CLane Xs{a.XA + b, a.cap};
-    const Lane Xd{a.x + b, a.cap};
-    for (int i = 0; i < a.N * M::NX; ++i) Xd.st(i, Xs.ld(i));
+    copy_traj<M>(slot_T<M>(a.TA, a.cap, (int)b), caller_dest<M>(a, (int)b), a.N - 1);
     a.status[b] = status;
 }
 
@@ -133,12 +159,12 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
     const int S = a.N - 1;
     bool need_ls = false, cont = false;
     const int id = a.idA[s];
-    const CLane X{a.XA + s, a.cap}, U{a.UA + s, a.cap};
+    const RecIn T = slot_T<M>(a.TA, a.cap, s);
     const int it = a.iters[id] + 1;                                                  // :46
     double deltaJ = 0.0, dmax = 0.0, maxq = a.maxq[id];
     int rr = 0, rs = 0;
-    const bool ok = backward_pass<M>(a.par, X, U, Lane{a.D + s, a.cap}, Lane{a.K + s, a.cap}, S, deltaJ, dmax, rr, rs,
-                                     maxq, live, lds);                               // :49
+    const bool ok = backward_pass<M>(a.par, T, RecOut{a.G + (long)s * Rec<M>::RG, a.cap * Rec<M>::RG}, S, deltaJ, dmax,
+                                     rr, rs, maxq, live, lds);                       // :49
     if (live) {
         a.iters[id] = it;
         a.maxq[id] = maxq;
@@ -160,7 +186,7 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
             if (!cont) a.status[id] = (dmax > a.d_tol) ? ILQR_EXIT_MAXITER : ILQR_EXIT_DTOL;
         }
         if (!need_ls)   // finished with the trajectory it came in with (:84)
-            copy_traj<M>(X, U, Lane{a.x + id, a.cap}, Lane{a.u + id, a.cap}, a.N);
+            copy_traj<M>(T, caller_dest<M>(a, id), S);
     }
     const int j = wave_append(need_ls, a.cnt + 1);
     const int ns = wave_append(cont, a.cnt + 0);
@@ -169,18 +195,6 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
         a.ls_dest[j] = cont ? ns : -1;
         if (cont) a.idB[ns] = id;
     }
-}
-
-// Where a line-search candidate is written: the trajectory's slot in the next
-// iteration's buffer, or straight into the caller's arrays when this was its
-// last iteration.
-struct Dest {
-    Lane X, U;
-};
-__device__ __forceinline__ Dest make_dest(const Pipe& a, int dest, int id)
-{
-    return dest >= 0 ? Dest{Lane{a.XB + dest, a.cap}, Lane{a.UB + dest, a.cap}}
-                     : Dest{Lane{a.x + id, a.cap}, Lane{a.u + id, a.cap}};
 }
 
 __device__ __forceinline__ void record_search(const Pipe& a, int id, int ls, bool complete, double Jn)
@@ -205,15 +219,14 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_forward1_kernel(Pipe a)
     bool need_bt = false;
     if (j < nls) {
         const int s = a.ls_slot[j], dest = a.ls_dest[j], id = a.idA[s];
-        const CLane X{a.XA + s, a.cap}, U{a.UA + s, a.cap};
-        const Dest d = make_dest(a, dest, id);
+        const RecIn T = slot_T<M>(a.TA, a.cap, s);
+        const Dest<M> d = make_dest<M>(a, dest, id);
         const double J = a.J[id], deltaJ = a.dJ[s];
-        const double Jn = forward_pass<M>(a.par, X, U, CLane{a.D + s, a.cap}, CLane{a.K + s, a.cap}, 1.0, d.X, d.U,
-                                          a.N - 1);                                    // :63-64
+        const double Jn = forward_pass<M>(a.par, T, slot_G<M>(a, s), 1.0, d, a.N - 1);  // :63-64
         const bool complete = (Jn - J <= -1e-2 * 1.0 * deltaJ) && (1 < a.max_ls);      // :66
         const bool abandon = (Jn != Jn) || (1 >= a.max_ls);                            // :67
         if (complete || abandon) {
-            if (!complete) copy_traj<M>(X, U, d.X, d.U, a.N);    // search abandoned: the trajectory is kept (:69-72)
+            if (!complete) copy_traj<M>(T, d, a.N - 1);    // search abandoned: the trajectory is kept (:69-72)
             record_search(a, id, 1, complete, Jn);
         } else {
             need_bt = true;
@@ -224,10 +237,9 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_forward1_kernel(Pipe a)
 }
 
 // ---------------------------------------------------------------- one more candidate for the entries of a list
-// Evaluation number `ls` (alpha = 0.5^(ls-1)) for every entry of `list_in`;
-// entries whose search goes on are appended to `list_out`.  Each level is one
-// launch over a compacted list, so a wavefront never waits for a trajectory
-// that needs more candidates than its neighbours.
+// Evaluation number `ls` (alpha = 0.5^(ls-1)) for every entry of `list_in`,
+// written; entries whose search goes on are appended to `list_out`.  (The
+// strictly sequential schedule, ILQR_FLAG_LS_SEQUENTIAL.)
 template <class M>
 __global__ __launch_bounds__(PIPE_WG) void pipe_forward_level_kernel(Pipe a, const int32_t* __restrict__ list_in,
                                                                      const int32_t* __restrict__ n_in,
@@ -240,15 +252,14 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_forward_level_kernel(Pipe a, con
     if (q < *n_in) {
         j = list_in[q];
         const int s = a.ls_slot[j], dest = a.ls_dest[j], id = a.idA[s];
-        const CLane X{a.XA + s, a.cap}, U{a.UA + s, a.cap};
-        const Dest d = make_dest(a, dest, id);
+        const RecIn T = slot_T<M>(a.TA, a.cap, s);
+        const Dest<M> d = make_dest<M>(a, dest, id);
         const double J = a.J[id], deltaJ = a.dJ[s];
-        const double Jn = forward_pass<M>(a.par, X, U, CLane{a.D + s, a.cap}, CLane{a.K + s, a.cap}, alpha, d.X, d.U,
-                                          a.N - 1);
+        const double Jn = forward_pass<M>(a.par, T, slot_G<M>(a, s), alpha, d, a.N - 1);
         const bool complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);   // :66
         const bool abandon = (Jn != Jn) || (ls >= a.max_ls);                           // :67
         if (complete || abandon) {
-            if (!complete) copy_traj<M>(X, U, d.X, d.U, a.N);
+            if (!complete) copy_traj<M>(T, d, a.N - 1);
             record_search(a, id, ls, complete, Jn);
         } else {
             more = true;
@@ -258,50 +269,88 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_forward_level_kernel(Pipe a, con
     if (more) list_out[o] = j;
 }
 
-// ---------------------------------------------------------------- remaining candidates side by side
-// G = max_ls - first_ls + 1 lanes per trajectory, lane g evaluates line-search
-// evaluation number first_ls + g (alpha = 0.5^(first_ls + g - 1)) without
-// storing it.  The search result is that of the first evaluation, in order, at
-// which the sequential loop would have stopped (:66-67); a wave-wide ballot
-// finds it, and the lane that owns it re-runs its forward pass to write the
-// accepted trajectory.
-template <class M>
-__global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_parallel_kernel(Pipe a, const int32_t* __restrict__ list_in,
-                                                                          const int32_t* __restrict__ n_in,
-                                                                          int first_ls)
+// ---------------------------------------------------------------- GL candidates per trajectory side by side
+// GL neighbouring lanes share one trajectory; lane g evaluates line-search
+// evaluation number first_ls + g (alpha = 0.5^(number - 1)), cost only.  The
+// search result is that of the first evaluation, in order, at which the
+// sequential loop would have stopped (:66-67); a ballot finds it and its
+// number and cost are left in win_ls / win_J for `commit`.  If none of the GL
+// stops: with REPEAT the same lanes go on with the next GL numbers (the last
+// number, max_ls, always stops), otherwise the entry is appended to list_out.
+template <class M, int GL, bool REPEAT>
+__global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_group_kernel(Pipe a, const int32_t* __restrict__ list_in,
+                                                                       const int32_t* __restrict__ n_in,
+                                                                       int32_t* __restrict__ list_out,
+                                                                       int32_t* __restrict__ n_out, int first_ls)
 {
-    const int G = a.max_ls - first_ls + 1;         // candidates per trajectory, 1 <= G <= 64
-    const int per_wave = 64 / G;
+    static_assert(64 % GL == 0, "whole groups per wavefront");
+    constexpr int PER_WAVE = 64 / GL;
     const int lane = threadIdx.x & 63;
-    const int grp = lane / G, g = lane - grp * G;
-    const int q = blockIdx.x * per_wave + grp;
-    const bool live = grp < per_wave && q < *n_in;
-    int s = 0, dest = -1, id = 0;
-    double J = 0.0, deltaJ = 0.0, Jn = 0.0, alpha = 1.0;
-    bool stop = false, complete = false;
-    const int ls = first_ls + g;
+    const int grp = lane / GL, g = lane % GL;
+    const int q = blockIdx.x * PER_WAVE + grp;
+    const bool live = q < *n_in;
+    int j = 0, s = 0;
+    double J = 0.0, deltaJ = 0.0;
     if (live) {
-        const int j = list_in[q];
-        s = a.ls_slot[j]; dest = a.ls_dest[j]; id = a.idA[s];
-        J = a.J[id]; deltaJ = a.dJ[s];
-        for (int i = 1; i < ls; ++i) alpha *= 0.5;
-        Jn = forward_cost<M>(a.par, CLane{a.XA + s, a.cap}, CLane{a.UA + s, a.cap}, CLane{a.D + s, a.cap},
-                             CLane{a.K + s, a.cap}, alpha, a.N - 1);
-        complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);
-        stop = complete || (Jn != Jn) || (ls >= a.max_ls);
+        j = list_in[q];
+        s = a.ls_slot[j];
+        J = a.J[a.idA[s]];
+        deltaJ = a.dJ[s];
     }
-    const unsigned long long stops = __ballot(stop);
-    if (!live) return;
-    const unsigned long long gmask = ((G >= 64) ? ~0ull : ((1ull << G) - 1ull)) << (grp * G);
-    const int first = __ffsll((long long)(stops & gmask)) - 1;     // always exists: the last candidate stops
-    if (lane != first) return;
-    const CLane X{a.XA + s, a.cap}, U{a.UA + s, a.cap};
-    const Dest d = make_dest(a, dest, id);
-    if (complete)
-        forward_pass<M>(a.par, X, U, CLane{a.D + s, a.cap}, CLane{a.K + s, a.cap}, alpha, d.X, d.U, a.N - 1);
-    else
-        copy_traj<M>(X, U, d.X, d.U, a.N);
-    record_search(a, id, ls, complete, Jn);
+    const unsigned long long gmask = ((GL >= 64) ? ~0ull : ((1ull << GL) - 1ull)) << (grp * GL);
+    bool pending = live;
+    for (int base = first_ls; __ballot(pending) != 0ull; base += GL) {
+        const int ls = base + g;
+        bool stop = false, complete = false;
+        double Jn = 0.0;
+        if (pending && ls <= a.max_ls) {
+            double alpha = 1.0;
+            for (int i = 1; i < ls; ++i) alpha *= 0.5;                                 // :73
+            Jn = forward_cost<M>(a.par, slot_T<M>(a.TA, a.cap, s), slot_G<M>(a, s), alpha, a.N - 1);
+            complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);          // :66
+            stop = complete || (Jn != Jn) || (ls >= a.max_ls);                         // :67
+        }
+        const unsigned long long stops = __ballot(stop) & gmask;
+        if (pending && stops) {
+            if (lane == __ffsll((long long)stops) - 1) {
+                a.win_ls[j] = complete ? ls : -ls;
+                a.win_J[j] = Jn;
+            }
+            pending = false;
+        }
+        if (!REPEAT) break;
+    }
+    if (!REPEAT) {
+        const int o = wave_append(pending && g == 0, n_out);
+        if (pending && g == 0) list_out[o] = j;
+    }
+}
+
+// ---------------------------------------------------------------- write what the backtracking searches decided
+// One lane per entry of the list of searches whose first candidate was
+// rejected: the accepted candidate is recomputed and written, or, when the
+// search was abandoned, the trajectory is carried over unchanged (:69-72).
+template <class M>
+__global__ __launch_bounds__(PIPE_WG) void pipe_commit_kernel(Pipe a, const int32_t* __restrict__ list_in,
+                                                              const int32_t* __restrict__ n_in)
+{
+    const int q = blockIdx.x * PIPE_WG + threadIdx.x;
+    if (q >= *n_in) return;
+    const int j = list_in[q];
+    const int s = a.ls_slot[j], dest = a.ls_dest[j], id = a.idA[s];
+    const int w = a.win_ls[j];
+    const bool complete = w > 0;
+    const int ls = complete ? w : -w;
+    const RecIn T = slot_T<M>(a.TA, a.cap, s);
+    const Dest<M> d = make_dest<M>(a, dest, id);
+    if (complete) {
+        double alpha = 1.0;
+        for (int i = 1; i < ls; ++i) alpha *= 0.5;
+        forward_pass<M>(a.par, T, slot_G<M>(a, s), alpha, d, a.N - 1);
+    } else {
+        copy_traj<M>(T, d, a.N - 1);
+    }
+    record_search(a, id, ls, complete, a.win_J[j]);
 }
 
 }  // namespace ilqr

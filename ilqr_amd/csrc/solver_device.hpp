@@ -2,9 +2,9 @@
 //
 // Each function restates one piece of control/iLQRController.py for a single
 // trajectory held by one lane; trajectory-sized data (x, u, d, K) lives in HBM
-// in a strided structure-of-arrays layout so that the 64 lanes of a wavefront
-// read and write consecutive doubles, and the small per-stage matrices live in
-// the lane's registers / private memory.
+// as per-stage records (see Rec below), the caller's arrays in a strided
+// structure-of-arrays layout, and the small per-stage matrices live in the
+// lane's registers / private memory.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
@@ -610,34 +610,120 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
 }
 
 // ------------------------------------------------------------------
+// Record layout of the solver's own trajectory buffers.  Everything one stage
+// of one trajectory needs sits in one contiguous, 64-byte aligned record:
+//     T record = [x_k (nx), u_k (nu), pad]        stage k of slot s at T[(k * cap + s) * RT]
+//     G record = [d_k (nu), K_k (nu * n), pad]    stage k of slot s at G[(k * cap + s) * RG]
+// A lane moves its record with 16-byte loads/stores.  When all 64 lanes of a
+// wavefront hold consecutive slots the wavefront touches one contiguous span;
+// when only a few scattered slots are still in use (later line-search
+// candidates) every 64-byte sector fetched is still fully used, which a
+// one-double-per-lane strided layout cannot offer (1/8 of each sector).
+// ------------------------------------------------------------------
+template <class M>
+struct Rec {
+    static constexpr int nx = M::NX, m = M::NU, n = M::NDX;
+    static constexpr int RT = (nx + m + 7) / 8 * 8;
+    static constexpr int RG = (m + m * n + 7) / 8 * 8;
+};
+
+struct RecIn {
+    const double* p;     // record of stage 0
+    long ss;             // doubles between consecutive stages
+};
+struct RecOut {
+    double* p;
+    long ss;
+};
+
+// CNT doubles from a 16-byte aligned record (reads one double of padding when CNT is odd)
+template <int CNT>
+__device__ __forceinline__ void load_rec(const double* p, double* v)
+{
+    const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+    for (int i = 0; i < CNT / 2; ++i) {
+        const double2 t = q[i];
+        v[2 * i] = t.x;
+        v[2 * i + 1] = t.y;
+    }
+    if constexpr (CNT & 1) v[CNT - 1] = q[CNT / 2].x;
+}
+template <int CNT>
+__device__ __forceinline__ void store_rec(double* p, const double* v)
+{
+    double2* q = reinterpret_cast<double2*>(p);
+#pragma unroll
+    for (int i = 0; i < CNT / 2; ++i) q[i] = make_double2(v[2 * i], v[2 * i + 1]);
+    if constexpr (CNT & 1) q[CNT / 2] = make_double2(v[CNT - 1], 0.0);
+}
+
+// Where a new trajectory goes: a slot of a record buffer, or the caller's
+// strided arrays x [N][nx][cs], u [S][nu][cs] at the trajectory's own index.
+template <class M>
+struct Dest {
+    static constexpr int nx = M::NX, m = M::NU;
+    double* t;
+    long ts;
+    double* x;
+    double* u;
+    long cs;
+    __device__ __forceinline__ void stage(int k, const double* xv, const double* uv) const
+    {
+        if (t) {
+            double r[nx + m];
+#pragma unroll
+            for (int i = 0; i < nx; ++i) r[i] = xv[i];
+#pragma unroll
+            for (int i = 0; i < m; ++i) r[nx + i] = uv[i];
+            store_rec<nx + m>(t + (long)k * ts, r);
+        } else {
+#pragma unroll
+            for (int i = 0; i < nx; ++i) x[(long)(k * nx + i) * cs] = xv[i];
+#pragma unroll
+            for (int i = 0; i < m; ++i) u[(long)(k * m + i) * cs] = uv[i];
+        }
+    }
+    __device__ __forceinline__ void last(int k, const double* xv) const
+    {
+        if (t) {
+            store_rec<nx>(t + (long)k * ts, xv);
+        } else {
+#pragma unroll
+            for (int i = 0; i < nx; ++i) x[(long)(k * nx + i) * cs] = xv[i];
+        }
+    }
+};
+
+// ------------------------------------------------------------------
 // Whole backward pass (iLQRController.py:98-123) for one trajectory per lane.
 // All 64 lanes of the wavefront call it together; a lane without a trajectory
-// (`active` false) only helps the others.  Writes d [S][m] and K [S][m*n];
-// returns deltaJ and max_k |d_k|_2 (with NumPy's NaN propagation, as
+// (`active` false) only helps the others.  Reads the T records, writes the G
+// records; returns deltaJ and max_k |d_k|_2 (with NumPy's NaN propagation, as
 // np.max(np.linalg.norm(d, axis=1)) has).  Returns false on LinAlgError.
 // ------------------------------------------------------------------
 template <class M>
-__device__ inline bool backward_pass(const double* par, const CLane& X, const CLane& U, const Lane& D, const Lane& K,
-                                     int S, double& deltaJ, double& dmax, int& regu_rounds, int& regu_stages,
-                                     double& maxq, bool active, double* lds)
+__device__ inline bool backward_pass(const double* par, const RecIn& T, const RecOut& G, int S, double& deltaJ,
+                                     double& dmax, int& regu_rounds, int& regu_stages, double& maxq, bool active,
+                                     double* lds)
 {
     using TR = typename TermsOf<M>::type;
     constexpr int n = M::NDX, m = M::NU, nx = M::NX;
-    double Vx[n], VL[n * (n + 1) / 2], xk[nx], uk[m], dk[m], Kk[m * n];
-    load_vec<nx>(X, S, xk);
-    TR::final_sym(par, xk, Vx, VL);
+    double Vx[n], VL[n * (n + 1) / 2], xu[nx + m], g[m + m * n];
+    double* const dk = g;
+    double* const Kk = g + m;
+    load_rec<nx>(T.p + (long)S * T.ss, xu);
+    TR::final_sym(par, xu, Vx, VL);
     double redu = 0.0, best = -INFINITY;
     bool anynan = false, ok = true;
     for (int k = S - 1; k >= 0; --k) {
-        load_vec<nx>(X, k, xk);
-        load_vec<m>(U, k, uk);
+        load_rec<nx + m>(T.p + (long)k * T.ss, xu);
         const bool alive = active && ok;
-        const bool good = backward_stage<M>(par, xk, uk, Vx, VL, dk, Kk, redu, regu_rounds, regu_stages, maxq, alive,
-                                            lds);
+        const bool good = backward_stage<M>(par, xu, xu + nx, Vx, VL, dk, Kk, redu, regu_rounds, regu_stages, maxq,
+                                            alive, lds);
         ok = ok && good;
         if (alive && good) {
-            store_vec<m>(D, k, dk);
-            store_vec<m * n>(K, k, Kk);
+            store_rec<m + m * n>(G.p + (long)k * G.ss, g);
             double s = 0.0;
             for (int i = 0; i < m; ++i) s += dk[i] * dk[i];
             double r = sqrt(s);
@@ -653,7 +739,7 @@ __device__ inline bool backward_pass(const double* par, const CLane& X, const CL
 // ------------------------------------------------------------------
 // Model.rollout + Model.cost_trj fused (model.py:15-20, :31-37): x written to
 // X, cost returned; the sum runs in the reference's order (stages 0..S-1, then
-// the final cost).
+// the final cost).  Strided arrays in and out.
 // ------------------------------------------------------------------
 template <class M>
 __device__ inline double rollout_cost(const double* par, const double* x0, const CLane& U, const Lane& X, int S)
@@ -674,47 +760,79 @@ __device__ inline double rollout_cost(const double* par, const double* x0, const
     return total;
 }
 
-// ------------------------------------------------------------------
-// _forward_pass (iLQRController.py:87-96) fused with cost_trj of the candidate
-// (:64): u_new = u + alpha d + K dx, x_new = f(x_new, u_new).  Candidate
-// trajectory is written to Xn/Un; its cost is returned.
-// ------------------------------------------------------------------
-template <class M, bool WRITE = true>
-__device__ inline double forward_pass(const double* par, const CLane& X, const CLane& U, const CLane& D,
-                                      const CLane& K, double alpha, const Lane& Xn, const Lane& Un, int S)
+// The same with the trajectory written as T records (u copied along).
+template <class M>
+__device__ inline double rollout_cost_rec(const double* par, const double* x0, const CLane& U, const Dest<M>& out, int S)
 {
-    constexpr int n = M::NDX, m = M::NU, nx = M::NX;
-    double xn[nx], xo[nx], xnext[nx], u[m], d[m], Kk[m * n], dx[n], un[m];
-    load_vec<nx>(X, 0, xn);
-    if (WRITE) store_vec<nx>(Xn, 0, xn);
+    constexpr int nx = M::NX, m = M::NU;
+    double x[nx], xn[nx], u[m];
+    for (int i = 0; i < nx; ++i) x[i] = x0[i];
     double total = 0.0;
     for (int k = 0; k < S; ++k) {
-        load_vec<nx>(X, k, xo);
         load_vec<m>(U, k, u);
-        load_vec<m>(D, k, d);
-        load_vec<m * n>(K, k, Kk);
-        M::diff_state(par, xn, xo, dx);
+        out.stage(k, x, u);
+        total += M::cost_stage(par, x, u);
+        M::dynamics(par, x, u, xn);
+        for (int i = 0; i < nx; ++i) x[i] = xn[i];
+    }
+    out.last(S, x);
+    total += M::cost_final(par, x);
+    return total;
+}
+
+// ------------------------------------------------------------------
+// _forward_pass (iLQRController.py:87-96) fused with cost_trj of the candidate
+// (:64): u_new = u + alpha d + K dx, x_new = f(x_new, u_new).  The candidate
+// is written to `out` when WRITE; its cost is returned.
+// ------------------------------------------------------------------
+template <class M, bool WRITE = true>
+__device__ inline double forward_pass(const double* par, const RecIn& T, const RecIn& G, double alpha,
+                                      const Dest<M>& out, int S)
+{
+    constexpr int n = M::NDX, m = M::NU, nx = M::NX;
+    double xn[nx], xu[nx + m], xnext[nx], g[m + m * n], dx[n], un[m];
+    load_rec<nx>(T.p, xn);
+    double total = 0.0;
+    for (int k = 0; k < S; ++k) {
+        load_rec<nx + m>(T.p + (long)k * T.ss, xu);
+        load_rec<m + m * n>(G.p + (long)k * G.ss, g);
+        const double* const d = g;
+        const double* const Kk = g + m;
+        M::diff_state(par, xn, xu, dx);
         for (int i = 0; i < m; ++i) {
             double s = 0.0;
             for (int t = 0; t < n; ++t) s += Kk[i * n + t] * dx[t];
-            un[i] = (u[i] + alpha * d[i]) + s;
+            un[i] = (xu[nx + i] + alpha * d[i]) + s;
         }
-        if (WRITE) store_vec<m>(Un, k, un);
+        if (WRITE) out.stage(k, xn, un);
         total += M::cost_stage(par, xn, un);
         M::dynamics(par, xn, un, xnext);
         for (int i = 0; i < nx; ++i) xn[i] = xnext[i];
-        if (WRITE) store_vec<nx>(Xn, k + 1, xn);
     }
+    if (WRITE) out.last(S, xn);
     total += M::cost_final(par, xn);
     return total;
 }
 
 // The same evaluation without storing the candidate (cost only).
 template <class M>
-__device__ inline double forward_cost(const double* par, const CLane& X, const CLane& U, const CLane& D,
-                                      const CLane& K, double alpha, int S)
+__device__ inline double forward_cost(const double* par, const RecIn& T, const RecIn& G, double alpha, int S)
 {
-    return forward_pass<M, false>(par, X, U, D, K, alpha, Lane{nullptr, 0}, Lane{nullptr, 0}, S);
+    return forward_pass<M, false>(par, T, G, alpha, Dest<M>{nullptr, 0, nullptr, nullptr, 0}, S);
+}
+
+// Copy of a trajectory (all T records) to `out`.
+template <class M>
+__device__ inline void copy_traj(const RecIn& T, const Dest<M>& out, int S)
+{
+    constexpr int nx = M::NX, m = M::NU;
+    double xu[nx + m];
+    for (int k = 0; k < S; ++k) {
+        load_rec<nx + m>(T.p + (long)k * T.ss, xu);
+        out.stage(k, xu, xu + nx);
+    }
+    load_rec<nx>(T.p + (long)S * T.ss, xu);
+    out.last(S, xu);
 }
 
 }  // namespace ilqr
