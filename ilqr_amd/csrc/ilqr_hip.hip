@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WG) void rollout_kernel(Dev a, const double* __rest
     const long st = a.p.stride;
     double xs[nx];
     for (int i = 0; i < nx; ++i) xs[i] = x0[(long)i * st + b];
-    double c = rollout_cost<M>(a.p.params, xs, CLane{u + b, st}, Lane{x + b, st}, a.p.N - 1);
+    double c = rollout_cost<M>(ParCache<M>(a.p.params).get(), xs, CLane{u + b, st}, Lane{x + b, st}, a.p.N - 1);
     if (J) J[b] = c;
 }
 
@@ -141,7 +141,7 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
 }
 
 struct WsLayout {
-    size_t TA, TB, G, dJ, J0, J, dmax, maxq, iters, status, regu_rounds, regu_stages, ls_total, idA, idB,
+    size_t TA, TB, G, Gscratch, dJ, J0, J, dmax, maxq, iters, status, regu_rounds, regu_stages, ls_total, idA, idB,
         ls_slot, ls_dest, bt, bt2, win_ls, win_J, cnt, total;
 };
 WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
@@ -153,6 +153,7 @@ WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
     WsLayout w;
     w.TA = take(N * RT * cap * 8); w.TB = take(N * RT * cap * 8);
     w.G = take(S * RG * cap * 8);
+    w.Gscratch = take(S * RG * 8);
     w.dJ = take(cap * 8);
     w.J0 = take(cap * 8); w.J = take(cap * 8); w.dmax = take(cap * 8); w.maxq = take(cap * 8);
     w.iters = take(cap * 4); w.status = take(cap * 4); w.regu_rounds = take(cap * 4); w.regu_stages = take(cap * 4);
@@ -191,7 +192,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     a.regu_stages = o.regu_stages ? o.regu_stages : (int32_t*)(ws + w.regu_stages);
     a.ls_total = o.ls_total ? o.ls_total : (int32_t*)(ws + w.ls_total);
     a.tr_ls = o.ls_evals; a.tr_acc = o.accepted; a.tr_J = o.J_trace; a.tr_dJ = o.deltaJ_trace;
-    a.TA = (double*)(ws + w.TA); a.TB = (double*)(ws + w.TB); a.G = (double*)(ws + w.G); a.dJ = (double*)(ws + w.dJ);
+    a.TA = (double*)(ws + w.TA); a.TB = (double*)(ws + w.TB); a.G = (double*)(ws + w.G); a.Gscratch = (double*)(ws + w.Gscratch); a.dJ = (double*)(ws + w.dJ);
     a.idA = (int32_t*)(ws + w.idA); a.idB = (int32_t*)(ws + w.idB);
     a.ls_slot = (int32_t*)(ws + w.ls_slot); a.ls_dest = (int32_t*)(ws + w.ls_dest);
     a.bt = (int32_t*)(ws + w.bt); a.bt2 = (int32_t*)(ws + w.bt2);

@@ -37,8 +37,8 @@ __device__ __forceinline__ void diff_sub(const double* s, const double* r, doubl
 struct CarModel {
     static constexpr int NX = 5, NU = 2, NDX = 5, NPAR = 2;
     static constexpr bool UNROLL = true;
-    // waves per SIMD the backward kernel is built for: asking for more makes the compiler spill the stage's
-    // matrices (measured: 1 -> 297 ms, 2 -> 334 ms, 3 -> 373 ms per 2^20 solves)
+    // waves per SIMD the backward kernel is built for: the stage's matrices need ~220 registers per lane, and
+    // asking for 3 or 4 waves makes the compiler spill ~1 KB per lane (measured slower than 2 resident waves)
     static constexpr int BACKWARD_WAVES = 1;
     __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
     {

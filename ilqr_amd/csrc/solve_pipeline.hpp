@@ -40,7 +40,8 @@
 
 namespace ilqr {
 
-constexpr int PIPE_WG = 64;
+constexpr int PIPE_WG = 64;      // one wavefront per workgroup: backward_stage exchanges data between lanes without barriers
+static_assert(PIPE_WG == 64, "backward_stage assumes single-wavefront workgroups");
 
 struct Pipe {
     // problem
@@ -61,6 +62,7 @@ struct Pipe {
     double *tr_J, *tr_dJ;
     // slot-indexed buffers
     double *TA, *TB, *G, *dJ;  // T records now / next iteration, G records, expected reduction
+    double* Gscratch;          // G records of one trajectory that lanes without a trajectory may write to
     int32_t *idA, *idB, *ls_slot, *ls_dest, *bt, *bt2;
     int32_t* win_ls;           // per line-search entry: evaluation number the search stopped at (< 0: not accepted)
     double* win_J;             // ... and that candidate's cost
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
     double xs[nx];
     for (int i = 0; i < nx; ++i) xs[i] = a.x0[(long)i * a.cap + b];
     const Dest<M> out{a.TA + b * Rec<M>::RT, a.cap * Rec<M>::RT, nullptr, nullptr, 0};
-    const double J = rollout_cost_rec<M>(a.par, xs, CLane{a.u + b, a.cap}, out, S);     // iLQRController.py:27-34
+    const double J = rollout_cost_rec<M>(ParCache<M>(a.par).get(), xs, CLane{a.u + b, a.cap}, out, S);     // iLQRController.py:27-34
     a.idA[b] = (int)b;
     a.J0[b] = J;
     a.J[b] = J;
@@ -163,8 +165,9 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
     const int it = a.iters[id] + 1;                                                  // :46
     double deltaJ = 0.0, dmax = 0.0, maxq = a.maxq[id];
     int rr = 0, rs = 0;
-    const bool ok = backward_pass<M>(a.par, T, RecOut{a.G + (long)s * Rec<M>::RG, a.cap * Rec<M>::RG}, S, deltaJ, dmax,
-                                     rr, rs, maxq, live, lds);                       // :49
+    const ParCache<M> par(a.par);
+    const RecOut G = live ? RecOut{a.G + (long)s * Rec<M>::RG, a.cap * Rec<M>::RG} : RecOut{a.Gscratch, Rec<M>::RG};
+    const bool ok = backward_pass<M>(par.get(), T, G, S, deltaJ, dmax, rr, rs, maxq, live, lds);     // :49
     if (live) {
         a.iters[id] = it;
         a.maxq[id] = maxq;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_forward1_kernel(Pipe a)
         const RecIn T = slot_T<M>(a.TA, a.cap, s);
         const Dest<M> d = make_dest<M>(a, dest, id);
         const double J = a.J[id], deltaJ = a.dJ[s];
-        const double Jn = forward_pass<M>(a.par, T, slot_G<M>(a, s), 1.0, d, a.N - 1);  // :63-64
+        const double Jn = forward_pass<M>(ParCache<M>(a.par).get(), T, slot_G<M>(a, s), 1.0, d, a.N - 1);  // :63-64
         const bool complete = (Jn - J <= -1e-2 * 1.0 * deltaJ) && (1 < a.max_ls);      // :66
         const bool abandon = (Jn != Jn) || (1 >= a.max_ls);                            // :67
         if (complete || abandon) {
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_forward_level_kernel(Pipe a, con
         const RecIn T = slot_T<M>(a.TA, a.cap, s);
         const Dest<M> d = make_dest<M>(a, dest, id);
         const double J = a.J[id], deltaJ = a.dJ[s];
-        const double Jn = forward_pass<M>(a.par, T, slot_G<M>(a, s), alpha, d, a.N - 1);
+        const double Jn = forward_pass<M>(ParCache<M>(a.par).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1);
         const bool complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);   // :66
         const bool abandon = (Jn != Jn) || (ls >= a.max_ls);                           // :67
         if (complete || abandon) {
@@ -297,6 +300,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_group_kernel(Pipe a, c
         J = a.J[a.idA[s]];
         deltaJ = a.dJ[s];
     }
+    const ParCache<M> par(a.par);
     const unsigned long long gmask = ((GL >= 64) ? ~0ull : ((1ull << GL) - 1ull)) << (grp * GL);
     bool pending = live;
     for (int base = first_ls; __ballot(pending) != 0ull; base += GL) {
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_group_kernel(Pipe a, c
         if (pending && ls <= a.max_ls) {
             double alpha = 1.0;
             for (int i = 1; i < ls; ++i) alpha *= 0.5;                                 // :73
-            Jn = forward_cost<M>(a.par, slot_T<M>(a.TA, a.cap, s), slot_G<M>(a, s), alpha, a.N - 1);
+            Jn = forward_cost<M>(par.get(), slot_T<M>(a.TA, a.cap, s), slot_G<M>(a, s), alpha, a.N - 1);
             complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);          // :66
             stop = complete || (Jn != Jn) || (ls >= a.max_ls);                         // :67
         }
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_commit_kernel(Pipe a, const int3
     if (complete) {
         double alpha = 1.0;
         for (int i = 1; i < ls; ++i) alpha *= 0.5;
-        forward_pass<M>(a.par, T, slot_G<M>(a, s), alpha, d, a.N - 1);
+        forward_pass<M>(ParCache<M>(a.par).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1);
     } else {
         copy_traj<M>(T, d, a.N - 1);
     }

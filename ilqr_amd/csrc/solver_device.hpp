@@ -44,6 +44,19 @@ __device__ __forceinline__ void store_vec(const Lane& a, int row, const double* 
 
 constexpr double PIVOT_TOL = 1e-13;
 
+// Ordering point for data that the lanes of ONE wavefront exchange through LDS.
+// The solver's workgroups are single wavefronts, whose LDS operations execute
+// in program order, so nothing has to be waited for: this only stops the
+// compiler from moving LDS accesses across it.  (__syncthreads() would also
+// drain every outstanding global load and store of the wavefront, which costs
+// a memory round trip per call.)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // np.linalg.inv of an m x m matrix (m <= 4) by Gauss-Jordan with row
 // pivoting.  Returns false when a pivot is exactly zero (NumPy: LinAlgError).
 template <int m>
@@ -382,7 +395,7 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
             const int rank = __popcll(pend & below);
             const bool src = need && rank < REGU_GROUPS;
             const int nsrc = min((int)__popcll(pend), REGU_GROUPS);
-            __syncthreads();
+            wave_sync();
             if (src) {
                 double PL[NL];
                 TR::regu_p(aux, PL);
@@ -392,7 +405,7 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
                     lds[rank * 2 * NL + NL + e] = PL[e];
                 }
             }
-            __syncthreads();
+            wave_sync();
             const int g = lane / REGU_BASE, c = lane % REGU_BASE;     // trajectory g, c + 1 rounds
             int t = 1;
             double mq = 0.0;
@@ -412,7 +425,7 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
             }
             res[lane * 2] = (double)t;
             res[lane * 2 + 1] = mq;
-            __syncthreads();
+            wave_sync();
             if (src) {
                 int cstar = -1, tt = 1;
                 double mqs = maxq;
@@ -466,7 +479,7 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
     while (stuck) {
         const int src = __ffsll((long long)stuck) - 1;
         stuck &= stuck - 1;
-        __syncthreads();
+        wave_sync();
         if (lane == src) {
             double PL[NL];
             TR::regu_p(aux, PL);
@@ -475,7 +488,7 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
                 lds[NL + e] = PL[e];
             }
         }
-        __syncthreads();
+        wave_sync();
         for (int base = REGU_BASE + 1;; base += 64) {
             const int rc = base + lane;
             const double coef = ldexp(1.0, rc) - ldexp(1.0, REGU_EXACT);
@@ -504,7 +517,7 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
                     res[0] = (double)t;
                     res[1] = mq;
                 }
-                __syncthreads();
+                wave_sync();
                 if (lane == src) {
                     const int rw = base + win;
                     const double cw = ldexp(1.0, rw) - ldexp(1.0, REGU_EXACT);
@@ -658,6 +671,28 @@ __device__ __forceinline__ void store_rec(double* p, const double* v)
     if constexpr (CNT & 1) q[CNT / 2] = make_double2(v[CNT - 1], 0.0);
 }
 
+// Plant parameters as the kernels read them: a small block is copied into
+// registers once per lane (a global load in the middle of a stage would make the
+// wavefront wait for every store it has in flight), a large one stays in memory.
+template <class M, bool SMALL = (M::NPAR <= 8)>
+struct ParCache;
+template <class M>
+struct ParCache<M, true> {
+    double v[M::NPAR];
+    __device__ __forceinline__ explicit ParCache(const double* p)
+    {
+#pragma unroll
+        for (int i = 0; i < M::NPAR; ++i) v[i] = p[i];
+    }
+    __device__ __forceinline__ const double* get() const { return v; }
+};
+template <class M>
+struct ParCache<M, false> {
+    const double* p;
+    __device__ __forceinline__ explicit ParCache(const double* q) : p(q) {}
+    __device__ __forceinline__ const double* get() const { return p; }
+};
+
 // Where a new trajectory goes: a slot of a record buffer, or the caller's
 // strided arrays x [N][nx][cs], u [S][nu][cs] at the trajectory's own index.
 template <class M>
@@ -698,8 +733,8 @@ struct Dest {
 // ------------------------------------------------------------------
 // Whole backward pass (iLQRController.py:98-123) for one trajectory per lane.
 // All 64 lanes of the wavefront call it together; a lane without a trajectory
-// (`active` false) only helps the others.  Reads the T records, writes the G
-// records; returns deltaJ and max_k |d_k|_2 (with NumPy's NaN propagation, as
+// (`active` false) only helps the others and must be given a G it may scribble
+// on.  Reads the T records, writes the G records; returns deltaJ and max_k |d_k|_2 (with NumPy's NaN propagation, as
 // np.max(np.linalg.norm(d, axis=1)) has).  Returns false on LinAlgError.
 // ------------------------------------------------------------------
 template <class M>
@@ -709,21 +744,30 @@ __device__ inline bool backward_pass(const double* par, const RecIn& T, const Re
 {
     using TR = typename TermsOf<M>::type;
     constexpr int n = M::NDX, m = M::NU, nx = M::NX;
-    double Vx[n], VL[n * (n + 1) / 2], xu[nx + m], g[m + m * n];
+    double Vx[n], VL[n * (n + 1) / 2], xu[nx + m], nxt[nx + m], g[m + m * n];
     double* const dk = g;
     double* const Kk = g + m;
     load_rec<nx>(T.p + (long)S * T.ss, xu);
+    load_rec<nx + m>(T.p + (long)(S - 1) * T.ss, nxt);
     TR::final_sym(par, xu, Vx, VL);
     double redu = 0.0, best = -INFINITY;
     bool anynan = false, ok = true;
+    // Nothing may still be in flight when the loop is entered: otherwise the wait-count bookkeeping of the
+    // loop has to allow for these loads on every trip and ends up waiting for the previous stage's stores.
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
     for (int k = S - 1; k >= 0; --k) {
-        load_rec<nx + m>(T.p + (long)k * T.ss, xu);
+        for (int i = 0; i < nx + m; ++i) xu[i] = nxt[i];
+        // the record of the next stage to be processed travels while this one is worked on
+        load_rec<nx + m>(T.p + (long)(k > 0 ? k - 1 : 0) * T.ss, nxt);
         const bool alive = active && ok;
         const bool good = backward_stage<M>(par, xu, xu + nx, Vx, VL, dk, Kk, redu, regu_rounds, regu_stages, maxq,
                                             alive, lds);
         ok = ok && good;
+        // stored by every lane, whatever its state (a lane without a trajectory is given a scratch record by
+        // the caller, a failed one writes gains nobody reads): with a fixed number of stores in flight behind
+        // the load above, waiting for that load does not mean waiting for the stores to reach memory
+        store_rec<m + m * n>(G.p + (long)k * G.ss, g);
         if (alive && good) {
-            store_rec<m + m * n>(G.p + (long)k * G.ss, g);
             double s = 0.0;
             for (int i = 0; i < m; ++i) s += dk[i] * dk[i];
             double r = sqrt(s);
@@ -790,12 +834,18 @@ __device__ inline double forward_pass(const double* par, const RecIn& T, const R
                                       const Dest<M>& out, int S)
 {
     constexpr int n = M::NDX, m = M::NU, nx = M::NX;
-    double xn[nx], xu[nx + m], xnext[nx], g[m + m * n], dx[n], un[m];
+    double xn[nx], xu[nx + m], xnext[nx], g[m + m * n], dx[n], un[m], xu2[nx + m], g2[m + m * n];
     load_rec<nx>(T.p, xn);
+    load_rec<nx + m>(T.p, xu2);
+    load_rec<m + m * n>(G.p, g2);
     double total = 0.0;
     for (int k = 0; k < S; ++k) {
-        load_rec<nx + m>(T.p + (long)k * T.ss, xu);
-        load_rec<m + m * n>(G.p + (long)k * G.ss, g);
+        for (int i = 0; i < nx + m; ++i) xu[i] = xu2[i];
+        for (int i = 0; i < m + m * n; ++i) g[i] = g2[i];
+        if (k + 1 < S) {     // the next stage's records travel while this stage is computed
+            load_rec<nx + m>(T.p + (long)(k + 1) * T.ss, xu2);
+            load_rec<m + m * n>(G.p + (long)(k + 1) * G.ss, g2);
+        }
         const double* const d = g;
         const double* const Kk = g + m;
         M::diff_state(par, xn, xu, dx);

@@ -278,6 +278,18 @@ static void forward_pass(const ilqr_oracle_model *M, const double *par, const do
 }
 
 /* iLQRController.py:98-123.  Returns 0, or -1 for the LinAlgError cases. */
+/* Diagnostics: histogram of regularisation rounds per stage (index 63 = 63 or more). */
+static long g_regu_hist[64];
+static int g_regu_hist_on = 0;
+void ilqr_oracle_regu_hist(int enable, long* out64)
+{
+    if (out64) memcpy(out64, g_regu_hist, sizeof(g_regu_hist));
+    if (enable >= 0) {
+        g_regu_hist_on = enable;
+        memset(g_regu_hist, 0, sizeof(g_regu_hist));
+    }
+}
+
 static int backward_pass(const ilqr_oracle_model *M, const double *par, const double *x, const double *u,
                          double *d, double *K, double *deltaJ, int S, ilqr_oracle_info *info)
 {
@@ -359,6 +371,11 @@ static int backward_pass(const ilqr_oracle_model *M, const double *par, const do
             full_hessian(Qxx, Qux, Quu, Q, n, nu);
             r += 1;
             info->regu_rounds += 1;
+        }
+        if (g_regu_hist_on) {
+            long* slot = &g_regu_hist[r < 63 ? r : 63];
+#pragma omp atomic
+            *slot += 1;
         }
         double *dk = d + k * nu, *Kk = K + k * nu * n;
         if (gains(Quu, Qu, Qux, dk, Kk, n, nu)) return -1;

@@ -66,4 +66,8 @@ int ilqr_oracle_solve_batch(int model_id, const double *par, int N, int max_iter
 const ilqr_oracle_model *ilqr_oracle_get_model(int model_id);
 int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W);
 void ilqr_oracle_model_dims(int model_id, int *nx, int *nu, int *ndx, int *npar);
+/* Diagnostics: copies the histogram of regularisation rounds per backward stage into out64 (if not NULL),
+ * then, when enable >= 0, clears it and switches the counting on (1) or off (0). */
+void ilqr_oracle_regu_hist(int enable, long* out64);
+
 #endif
