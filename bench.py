@@ -14,9 +14,13 @@ its own shard with no data-path collective, then the per-trajectory costs / iter
 counts / exit codes are all-gathered over RCCL, which is the path's only exchange.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline:     algorithmic fp64 flops of the solves (dense formulas, actual per-trajectory
-                iteration / regularisation / line-search counts) / kernel time vs the fp64
-                vector peak, plus the same for algorithmic bytes vs HBM peak;
+  roofline:     the dominant kernel, the backward pass (pipe_backward_kernel): algorithmic fp64
+                flops of the backward passes actually run (dense formulas, the batch's own
+                iteration / regularisation counts) / that kernel's summed device time in one
+                solve, timed with HIP events around each of its launches on the solve's stream
+                (ILQR_FLAG_TIMING, one extra solve after the timed region), against the fp64
+                peak.  `line_search` gives the same for the memory-bound forward-pass kernels
+                against the HBM peak, `solve` for all kernels of a solve together;
   cpu_baseline: the CPU checker (oracle/, a C restatement of the reference solver) on a
                 bounded sample of the same batch, one OpenMP thread per host core.
 """
@@ -34,7 +38,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: half the 157.3 TFLOP/s fp32 vector peak (non-MFMA)
+FP64_PEAK_TFLOPS = 78.6          # MI355X fp64: matrix (MFMA) peak = vector peak = half the 157.3 TFLOP/s fp32 rate
 HBM_PEAK_GBS = 8000.0
 
 
@@ -48,7 +52,8 @@ def car_inputs(B, seed):
 
 def algorithmic_flops(n, m, S, ops, iters, regu_rounds, regu_stages, ls_total, B):
     """Dense flop count of the solves actually performed (FMA = 2, sin/cos/tan/sqrt/div = 1, no
-    sparsity or symmetry credit); sums over the batch are passed in."""
+    sparsity or symmetry credit); sums over the batch are passed in.  Returns (initial rollouts,
+    backward passes, line-search forward passes)."""
     F_dyn, F_cost, F_costf = ops["dyn"]["flops"], ops["cost_stage"]["flops"], ops["cost_final"]["flops"]
     F_deriv = ops["stage"]["flops"]
     base = (4 * n**3 + 8 * n * n * m + 6 * n * m * m + m**3 / 3 + (n + m) ** 3 / 3 + 6 * n * n + 9 * n * m + 5 * m * m
@@ -56,15 +61,23 @@ def algorithmic_flops(n, m, S, ops, iters, regu_rounds, regu_stages, ls_total, B
     per_round = (n + m) ** 3 / 3 + 2 * (n * n + n * m + m * m)
     per_regu_stage = 2 * n**3 + 2 * n * n * m + 2 * n * m * m
     F_fwd = n + 2 * m * n + 3 * m + F_dyn + F_cost
-    total = B * (S * (F_dyn + F_cost) + F_costf)
-    total += iters * (S * base + ops["final"]["flops"]) + regu_rounds * per_round + regu_stages * per_regu_stage
-    total += ls_total * (S * F_fwd + F_costf)
-    return float(total)
+    init = B * (S * (F_dyn + F_cost) + F_costf)
+    backward = iters * (S * base + ops["final"]["flops"]) + regu_rounds * per_round + regu_stages * per_regu_stage
+    forward = ls_total * (S * F_fwd + F_costf)
+    return float(init), float(backward), float(forward)
 
 
-def algorithmic_bytes(nx, m, N, B):
+def algorithmic_bytes(nx, n, m, N, B, iters, ls_total, ls_searches):
+    """Bytes a solve has to move when every pass streams its operands once (8-byte doubles, no padding):
+    the caller's x0, u in and x, u, J out; per backward pass x, u in and d, K out; per line-search
+    evaluation x, u, d, K in; per search the accepted x, u out.  Returns (solve total, backward, line search)."""
     S = N - 1
-    return float(B * (8 * (nx + S * m) + 8 * (N * nx + S * m + 1) + 12))
+    traj = N * nx + S * m
+    gains = S * (m + m * n)
+    io = B * (8 * (nx + S * m) + 8 * (traj + 1) + 12)
+    backward = iters * 8 * (traj + gains)
+    forward = ls_total * 8 * (traj + gains) + ls_searches * 8 * traj
+    return float(io + backward + forward), float(backward), float(forward)
 
 
 def main():
@@ -73,7 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1 << 20, help="trajectories per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=16384, help="trajectories timed on the host cores (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 20, help="trajectories timed on the host cores (0 = skip)")
     ap.add_argument("--check", type=int, default=2048, help="trajectories checked against the CPU checker (0 = skip)")
     a = ap.parse_args()
 
@@ -135,6 +148,14 @@ def main():
         elapsed = float(t.item())
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
 
+    # one more solve with an event pair around every kernel launch (outside the timed region)
+    from ilqr_amd import _lib
+    solver.flags |= _lib.FLAG_TIMING
+    step()
+    sync()
+    phases = solver.last_timing()
+    solver.flags &= ~_lib.FLAG_TIMING
+
     # counts of the work actually done (rank 0's shard; every shard is statistically alike)
     iters = int(out["iters"].sum().item())
     regu_rounds = int(out["regu_rounds"].sum().item())
@@ -144,15 +165,23 @@ def main():
 
     if rank == 0:
         ops = json.load(open(os.path.join(ROOT, "ilqr_amd", "csrc", "gen", "opcounts.json")))["car"]
-        flops = algorithmic_flops(n, m, S, ops, iters, regu_rounds, regu_stages, ls_total, B)
-        byts = algorithmic_bytes(nx, m, N, B)
+        # every iteration that got past the deltaJ test ran one search: iterations minus the ones that ended a solve
+        # in the backward kernel (deltaJ < 1 or a LinAlgError)
+        searches = iters - status[1] - status[3]
+        f_init, f_bwd, f_fwd = algorithmic_flops(n, m, S, ops, iters, regu_rounds, regu_stages, ls_total, B)
+        b_all, b_bwd, b_fwd = algorithmic_bytes(nx, n, m, N, B, iters, ls_total, searches)
+        flops = f_init + f_bwd + f_fwd
         tfl = flops / (kernel_ms * 1e-3) / 1e12
-        gbs = byts / (kernel_ms * 1e-3) / 1e9
+        gbs = b_all / (kernel_ms * 1e-3) / 1e9
+        bw_ms, bw_launches = phases["backward"]
+        ls_ms = phases["forward1"][0] + phases["backtrack"][0] + phases["commit"][0]
+        bw_tfl = f_bwd / (bw_ms * 1e-3) / 1e12
+        ls_gbs = b_fwd / (ls_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath))
             except Exception:
                 traffic = None
         value = world * B * a.steps / elapsed
@@ -166,11 +195,25 @@ def main():
             "ms_per_iter": 1e3 * elapsed / a.steps / max(iters / B, 1e-9),
             "mean_iters": iters / B, "mean_ls_evals": ls_total / B, "mean_regu_rounds": regu_rounds / B,
             "exit_counts": {"d_tol": status[0], "deltaJ<1": status[1], "max_iter": status[2], "linalg": status[3]},
-            "roofline": {"bound": "valu_fp64", "achieved": tfl, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tfl / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
-                         "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                 "algorithmic_bytes_per_launch": byts}},
+            "roofline": {"kernel": "pipe_backward_kernel<CarModel>", "bound": "mfma",
+                         "bound_note": "fp64 arithmetic on the vector ALUs (7x7 per-lane matrices, no MFMA); on MI355X "
+                                       "the fp64 vector peak equals the fp64 matrix peak",
+                         "achieved": bw_tfl, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": bw_tfl / FP64_PEAK_TFLOPS,
+                         "traffic": (traffic or {}).get("backward_hbm_bytes_per_solve"),
+                         "launches_per_solve": bw_launches, "kernel_ms_per_solve": bw_ms,
+                         "avg_launch_ms": bw_ms / max(bw_launches, 1), "algorithmic_flops_per_solve": f_bwd,
+                         "line_search": {"kernels": "pipe_forward1 / pipe_backtrack_group / pipe_commit", "bound": "hbm",
+                                         "achieved": ls_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": ls_gbs / HBM_PEAK_GBS,
+                                         "traffic": (traffic or {}).get("line_search_hbm_bytes_per_solve"),
+                                         "kernel_ms_per_solve": ls_ms, "algorithmic_bytes_per_solve": b_fwd},
+                         "solve": {"kernel_ms": kernel_ms, "tflops": tfl, "frac_fp64_peak": tfl / FP64_PEAK_TFLOPS,
+                                   "gbs": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS, "algorithmic_flops": flops,
+                                   "algorithmic_bytes": b_all,
+                                   "traffic": (traffic or {}).get("solve_hbm_bytes")},
+                         "phase_ms": {k: v[0] for k, v in phases.items() if k != "iterations"},
+                         "phase_launches": {k: v[1] for k, v in phases.items() if k != "iterations"}},
         }
         # ---- parity spot check and CPU baseline (rank 0, N=1 only for the baseline) ----
         if a.check or (a.cpu_sample and world == 1):

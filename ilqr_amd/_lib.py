@@ -17,9 +17,11 @@ EXIT_DTOL, EXIT_SMALL_DELTAJ, EXIT_MAXITER, EXIT_LINALG = 0, 1, 2, 3
 EXIT_NAMES = {0: "d_tol", 1: "deltaJ<1", 2: "max_iter", 3: "linalg_error"}
 FLAG_PARALLEL_LS = 1
 FLAG_LS_SEQUENTIAL = 2
+FLAG_TIMING = 4
+PHASES = ("init", "backward", "forward1", "backtrack", "commit")
 
 EXPORTS = ("ilqr_model_info", "ilqr_workspace_bytes", "ilqr_solve_batch", "ilqr_rollout_cost",
-           "ilqr_model_eval", "ilqr_mpc_advance", "ilqr_last_error", "ilqr_version")
+           "ilqr_model_eval", "ilqr_mpc_advance", "ilqr_last_timing", "ilqr_last_error", "ilqr_version")
 
 _dp = C.c_void_p  # device pointers travel as plain addresses
 
@@ -33,6 +35,10 @@ class Problem(C.Structure):
 class Outputs(C.Structure):
     _fields_ = [(k, _dp) for k in ("J0", "J", "dmax", "max_abs_q", "iters", "status", "regu_rounds", "ls_total",
                                    "regu_stages", "ls_evals", "accepted", "J_trace", "deltaJ_trace")]
+
+
+class Timing(C.Structure):
+    _fields_ = [("ms", C.c_double * 5), ("launches", C.c_int32 * 5), ("iterations", C.c_int32), ("pad_", C.c_int32 * 2)]
 
 
 class LibraryMissing(RuntimeError):
@@ -64,6 +70,8 @@ def lib():
     L.ilqr_model_eval.argtypes = [C.POINTER(Problem)] + [_dp] * 15
     L.ilqr_mpc_advance.restype = C.c_int
     L.ilqr_mpc_advance.argtypes = [C.POINTER(Problem), _dp, _dp, _dp]
+    L.ilqr_last_timing.restype = C.c_int
+    L.ilqr_last_timing.argtypes = [C.POINTER(Timing)]
     L.ilqr_last_error.restype = C.c_char_p
     L.ilqr_version.restype = C.c_char_p
     _lib = L

@@ -128,6 +128,15 @@ class BatchSolver:
                                              ws.numel(), self._stream()))
         return x, u, out
 
+    def last_timing(self) -> dict:
+        """Device time per kernel phase of this thread's last solve made with FLAG_TIMING:
+        {phase: (milliseconds, launches)} plus "iterations"."""
+        t = _lib.Timing()
+        _lib.check(self.lib.ilqr_last_timing(C.byref(t)))
+        d = {name: (float(t.ms[i]), int(t.launches[i])) for i, name in enumerate(_lib.PHASES)}
+        d["iterations"] = int(t.iterations)
+        return d
+
     # ------------------------------------------------------ trajectory-major
     def _to_dev(self, a):
         t = torch.as_tensor(np.asarray(a, dtype=np.float64)) if not torch.is_tensor(a) else a

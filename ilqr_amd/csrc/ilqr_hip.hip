@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/ilqr_hip.h"
 #include "solver_device.hpp"
 #include "solve_pipeline.hpp"
@@ -166,6 +168,51 @@ WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
     return w;
 }
 
+// ILQR_FLAG_TIMING: a pair of events around every launch, summed per phase when the solve is over.
+thread_local ilqr_timing g_timing;
+thread_local bool g_timing_valid = false;
+thread_local std::vector<hipEvent_t> g_events;
+
+struct PhaseTimer {
+    bool on;
+    hipStream_t st;
+    size_t used = 0;
+    std::vector<int> phase;
+    PhaseTimer(bool enable, hipStream_t s) : on(enable), st(s) {}
+    void begin(int ph)
+    {
+        if (!on) return;
+        while (g_events.size() < used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+            g_events.push_back(e);
+        }
+        phase.push_back(ph);
+        (void)hipEventRecord(g_events[used], st);
+    }
+    void end()
+    {
+        if (!on) return;
+        (void)hipEventRecord(g_events[used + 1], st);
+        used += 2;
+    }
+    int finish(int iterations)
+    {
+        if (!on) return ILQR_OK;
+        HIP_TRY(hipStreamSynchronize(st));
+        memset(&g_timing, 0, sizeof(g_timing));
+        for (size_t i = 0; i < phase.size() && 2 * i + 1 < used + 1; ++i) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, g_events[2 * i], g_events[2 * i + 1]));
+            g_timing.ms[phase[i]] += ms;
+            g_timing.launches[phase[i]] += 1;
+        }
+        g_timing.iterations = iterations;
+        g_timing_valid = true;
+        return ILQR_OK;
+    }
+};
+
 inline unsigned blocks_for(long n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 // run_ilqr for the whole batch: see solve_pipeline.hpp.  Blocks the calling thread on `stream`
@@ -199,14 +246,17 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     a.win_ls = (int32_t*)(ws + w.win_ls); a.win_J = (double*)(ws + w.win_J);
     a.cnt = (int32_t*)(ws + w.cnt);
 
+    PhaseTimer tm((a.flags & ILQR_FLAG_TIMING) != 0, st);
+    tm.begin(ILQR_PHASE_INIT);
     hipLaunchKernelGGL(pipe_init_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+    tm.end();
     HIP_TRY(hipGetLastError());
     // the loop test of iLQRController.py:43 before the first iteration: max|d| is +inf there
     if (!(INFINITY > a.d_tol) || !(0 < a.max_iter)) {
         const int status = !(INFINITY > a.d_tol) ? ILQR_EXIT_DTOL : ILQR_EXIT_MAXITER;
         hipLaunchKernelGGL(pipe_finish_all_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a, status);
         HIP_TRY(hipGetLastError());
-        return ILQR_OK;
+        return tm.finish(0);
     }
     // Line-search schedule after evaluation 1 (all three give bit-identical results):
     //   default                  evaluations 2..5 four lanes per trajectory, then 6.. sixteen at a time, commit
@@ -215,17 +265,23 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     constexpr int GA = 4, GB = 16;
     int32_t h[4];
     long count = a.B;
+    int iters_run = 0;
     for (int iter = 1; iter <= a.max_iter && count > 0; ++iter) {
+        iters_run = iter;
         a.count = (int)count;
         a.iter = iter;
         HIP_TRY(hipMemsetAsync(a.cnt, 0, 64 * sizeof(int32_t), st));
+        tm.begin(ILQR_PHASE_BACKWARD);
         hipLaunchKernelGGL(pipe_backward_kernel<M>, dim3(blocks_for(count, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+        tm.end();
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h, a.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const long next = h[0], nls = h[1];
         if (nls > 0) {
+            tm.begin(ILQR_PHASE_FORWARD1);
             hipLaunchKernelGGL(pipe_forward1_kernel<M>, dim3(blocks_for(nls, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+            tm.end();
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h + 2, a.cnt + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -234,8 +290,10 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
                 int32_t *lin = a.bt, *lout = a.bt2;
                 double alpha = 0.5;
                 for (int ls = 2; bound > 0 && ls <= a.max_ls; ++ls, alpha *= 0.5) {
+                    tm.begin(ILQR_PHASE_BACKTRACK);
                     hipLaunchKernelGGL(pipe_forward_level_kernel<M>, dim3(blocks_for(bound, PIPE_WG)), dim3(PIPE_WG), 0,
                                        st, a, lin, a.cnt + ls, lout, a.cnt + ls + 1, ls, alpha);
+                    tm.end();
                     HIP_TRY(hipGetLastError());
                     int32_t* t = lin; lin = lout; lout = t;
                     if ((ls % 4) == 0) {     // tighten the bound now and then
@@ -249,18 +307,24 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
                 const int32_t* nin = a.cnt + 2;
                 int first = 2;
                 if (!(a.flags & ILQR_FLAG_PARALLEL_LS)) {
+                    tm.begin(ILQR_PHASE_BACKTRACK);
                     hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GA, false>), dim3(blocks_for(bound, 64 / GA)),
                                        dim3(PIPE_WG), 0, st, a, lin, nin, a.bt2, a.cnt + 3, first);
+                    tm.end();
                     HIP_TRY(hipGetLastError());
                     lin = a.bt2; nin = a.cnt + 3; first += GA;
                 }
                 if (first <= a.max_ls) {
+                    tm.begin(ILQR_PHASE_BACKTRACK);
                     hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GB, true>), dim3(blocks_for(bound, 64 / GB)),
                                        dim3(PIPE_WG), 0, st, a, lin, nin, (int32_t*)nullptr, (int32_t*)nullptr, first);
+                    tm.end();
                     HIP_TRY(hipGetLastError());
                 }
+                tm.begin(ILQR_PHASE_COMMIT);
                 hipLaunchKernelGGL(pipe_commit_kernel<M>, dim3(blocks_for(bound, PIPE_WG)), dim3(PIPE_WG), 0, st, a,
                                    a.bt, a.cnt + 2);
+                tm.end();
                 HIP_TRY(hipGetLastError());
             }
         }
@@ -269,7 +333,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
         int32_t* ti = a.idA; a.idA = a.idB; a.idB = ti;
         count = next;
     }
-    return ILQR_OK;
+    return tm.finish(iters_run);
 }
 
 template <class F>
@@ -289,7 +353,15 @@ int dispatch(int model_id, F&& f)
 extern "C" {
 
 const char* ilqr_last_error(void) { return g_err; }
-const char* ilqr_version(void) { return "ilqr_hip 0.1 (gfx950)"; }
+const char* ilqr_version(void) { return "ilqr_hip 0.2 (gfx950)"; }
+
+int ilqr_last_timing(ilqr_timing* out)
+{
+    if (!out) return fail(ILQR_E_BADARG, "out is NULL");
+    if (!g_timing_valid) return fail(ILQR_E_BADARG, "no ilqr_solve_batch call with ILQR_FLAG_TIMING on this thread yet");
+    *out = g_timing;
+    return ILQR_OK;
+}
 
 int ilqr_model_info(int32_t model_id, int32_t* nx, int32_t* nu, int32_t* ndx, int32_t* npar)
 {

@@ -58,14 +58,35 @@ typedef struct {
     int32_t flags;        /* ILQR_FLAG_* */
 } ilqr_problem;
 
-/* Line-search evaluation schedule (the result does not depend on it):
- * default: candidate 1 (alpha = 1) for every trajectory, candidates 2 and 3 one launch each for those
- * still searching, then all remaining candidates side by side, one lane each, first stopping one wins. */
+/* Line-search evaluation schedule (the result does not depend on it, bit for bit):
+ * default: candidate 1 (alpha = 1) for every trajectory; for those it was rejected for, candidates 2..5 in four
+ * neighbouring lanes, then candidates 6.. sixteen at a time (cost only, the first one at which the reference's
+ * loop would stop wins), then one pass that writes the trajectory each search ended with. */
 enum {
     ILQR_FLAG_NONE = 0,
-    ILQR_FLAG_PARALLEL_LS = 1,   /* side by side right after alpha = 1 was rejected */
-    ILQR_FLAG_LS_SEQUENTIAL = 2  /* never side by side: one launch per candidate */
+    ILQR_FLAG_PARALLEL_LS = 1,   /* sixteen at a time right after alpha = 1 was rejected */
+    ILQR_FLAG_LS_SEQUENTIAL = 2, /* never side by side: one launch per candidate (max_ls <= 60) */
+    ILQR_FLAG_TIMING = 4         /* bracket every kernel launch with HIP events: see ilqr_last_timing() */
 };
+
+/* Kernel phases of ilqr_solve_batch, for ilqr_timing. */
+enum {
+    ILQR_PHASE_INIT = 0,      /* rollout + cost of the initial guess      (iLQRController.py:27-34) */
+    ILQR_PHASE_BACKWARD = 1,  /* backward passes and exit tests           (:43-51, :98-123) */
+    ILQR_PHASE_FORWARD1 = 2,  /* first line-search candidate, alpha = 1   (:60-68, :87-96) */
+    ILQR_PHASE_BACKTRACK = 3, /* later candidates (cost only or one launch per candidate) */
+    ILQR_PHASE_COMMIT = 4,    /* writing the trajectory a backtracking search ended with */
+    ILQR_PHASE_COUNT = 5
+};
+
+/* host struct: device time and launch count per phase of the last ilqr_solve_batch call that the calling
+ * thread made with ILQR_FLAG_TIMING (HIP events on the call's stream around every launch). */
+typedef struct {
+    double ms[ILQR_PHASE_COUNT];
+    int32_t launches[ILQR_PHASE_COUNT];
+    int32_t iterations;   /* solver iterations the batch ran (the longest trajectory's) */
+    int32_t pad_[2];
+} ilqr_timing;
 
 /* per-trajectory results; any pointer may be NULL.  Arrays are [B] (index b),
  * traces are [trace_len][stride] (index it * stride + b). */
@@ -124,6 +145,10 @@ int ilqr_model_eval(const ilqr_problem *p, const double *xs, const double *us, d
  * control/AcrobotControllers.py:60-63): x0 <- discrete_dynamics(x0, u[0]) and
  * u[:-1] <- u[1:] (last row kept), in place, for B trajectories. */
 int ilqr_mpc_advance(const ilqr_problem *p, double *x0, double *u, void *stream);
+
+/* No counterpart in the reference (measurement aid): copies the timing of the calling thread's last
+ * ilqr_solve_batch call made with ILQR_FLAG_TIMING into *out (host pointer).  Returns ILQR_E_BADARG if there is none. */
+int ilqr_last_timing(ilqr_timing *out);
 
 /* message for the last error on the calling thread (host pointer, never NULL) */
 const char *ilqr_last_error(void);
