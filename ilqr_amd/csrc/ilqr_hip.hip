@@ -144,12 +144,12 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
 
 struct WsLayout {
     size_t TA, TB, G, Gscratch, dJ, J0, J, dmax, maxq, iters, status, regu_rounds, regu_stages, ls_total, idA, idB,
-        ls_slot, ls_dest, bt, bt2, win_ls, win_J, cnt, total;
+        ls_slot, ls_dest, bt, bt2, ls_from, pred, win_ls, win_J, cnt, total;
 };
 WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
 {
     const size_t cap = (size_t)p->stride, S = (size_t)p->N - 1, N = (size_t)p->N;
-    const size_t RT = (size_t)(d.nx + d.nu + 7) / 8 * 8, RG = (size_t)(d.nu + d.nu * d.ndx + 7) / 8 * 8;   // Rec<M>
+    const size_t RT = (size_t)(d.nx + d.nu + 7) / 8 * 8, RG = (size_t)(d.nu + d.nu * d.ndx + 1) / 2 * 2;   // Rec<M>
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     WsLayout w;
@@ -162,6 +162,7 @@ WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
     w.ls_total = take(cap * 4);
     w.idA = take(cap * 4); w.idB = take(cap * 4); w.ls_slot = take(cap * 4); w.ls_dest = take(cap * 4);
     w.bt = take(cap * 4); w.bt2 = take(cap * 4);
+    w.ls_from = take(cap * 4); w.pred = take(cap * 4);
     w.win_ls = take(cap * 4); w.win_J = take(cap * 8);
     w.cnt = take(64 * 4);
     w.total = off;
@@ -221,7 +222,7 @@ template <class M>
 int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, const ilqr_outputs* out, char* ws,
                  const WsLayout& w, hipStream_t st)
 {
-    static_assert(Rec<M>::RT == (M::NX + M::NU + 7) / 8 * 8 && Rec<M>::RG == (M::NU + M::NU * M::NDX + 7) / 8 * 8, "");
+    static_assert(Rec<M>::RT == (M::NX + M::NU + 7) / 8 * 8 && Rec<M>::RG == (M::NU + M::NU * M::NDX + 1) / 2 * 2, "");
     Pipe a;
     memset(&a, 0, sizeof(a));
     a.N = p->N; a.max_iter = p->max_iter; a.max_ls = p->max_ls; a.trace_len = p->trace_len; a.flags = p->flags;
@@ -243,6 +244,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     a.idA = (int32_t*)(ws + w.idA); a.idB = (int32_t*)(ws + w.idB);
     a.ls_slot = (int32_t*)(ws + w.ls_slot); a.ls_dest = (int32_t*)(ws + w.ls_dest);
     a.bt = (int32_t*)(ws + w.bt); a.bt2 = (int32_t*)(ws + w.bt2);
+    a.ls_from = (int32_t*)(ws + w.ls_from); a.pred = (int32_t*)(ws + w.pred);
     a.win_ls = (int32_t*)(ws + w.win_ls); a.win_J = (double*)(ws + w.win_J);
     a.cnt = (int32_t*)(ws + w.cnt);
 
@@ -262,7 +264,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     //   default                  evaluations 2..5 four lanes per trajectory, then 6.. sixteen at a time, commit
     //   ILQR_FLAG_PARALLEL_LS    evaluations 2.. sixteen at a time, commit
     //   ILQR_FLAG_LS_SEQUENTIAL  one launch per evaluation over the compacted list of those still searching
-    constexpr int GA = 4, GB = 16;
+    constexpr int GA = 8, GB = 16;
     int32_t h[4];
     long count = a.B;
     int iters_run = 0;
@@ -305,19 +307,20 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
             } else if (bound > 0 && a.max_ls >= 2) {
                 const int32_t* lin = a.bt;
                 const int32_t* nin = a.cnt + 2;
-                int first = 2;
+                bool more = true;       // can an entry still be searching after the launches so far?
                 if (!(a.flags & ILQR_FLAG_PARALLEL_LS)) {
                     tm.begin(ILQR_PHASE_BACKTRACK);
                     hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GA, false>), dim3(blocks_for(bound, 64 / GA)),
-                                       dim3(PIPE_WG), 0, st, a, lin, nin, a.bt2, a.cnt + 3, first);
+                                       dim3(PIPE_WG), 0, st, a, lin, nin, a.bt2, a.cnt + 3);
                     tm.end();
                     HIP_TRY(hipGetLastError());
-                    lin = a.bt2; nin = a.cnt + 3; first += GA;
+                    lin = a.bt2; nin = a.cnt + 3;
+                    more = a.max_ls > GA;     // an entry that started at evaluation 1 goes on with number GA + 1
                 }
-                if (first <= a.max_ls) {
+                if (more) {
                     tm.begin(ILQR_PHASE_BACKTRACK);
                     hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GB, true>), dim3(blocks_for(bound, 64 / GB)),
-                                       dim3(PIPE_WG), 0, st, a, lin, nin, (int32_t*)nullptr, (int32_t*)nullptr, first);
+                                       dim3(PIPE_WG), 0, st, a, lin, nin, (int32_t*)nullptr, (int32_t*)nullptr);
                     tm.end();
                     HIP_TRY(hipGetLastError());
                 }

@@ -64,6 +64,8 @@ struct Pipe {
     double *TA, *TB, *G, *dJ;  // T records now / next iteration, G records, expected reduction
     double* Gscratch;          // G records of one trajectory that lanes without a trajectory may write to
     int32_t *idA, *idB, *ls_slot, *ls_dest, *bt, *bt2;
+    int32_t* ls_from;          // per line-search entry: number of the first evaluation still to be made
+    int32_t* pred;             // per trajectory id: 1 if its last search rejected alpha = 1
     int32_t* win_ls;           // per line-search entry: evaluation number the search stopped at (< 0: not accepted)
     double* win_J;             // ... and that candidate's cost
     int32_t* cnt;              // [0] slots handed out in B, [1] line-search entries, [2] rejected at alpha = 1,
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
     a.regu_rounds[b] = 0;
     a.regu_stages[b] = 0;
     a.ls_total[b] = 0;
+    a.pred[b] = 0;
 }
 
 // The loop test of :43 failed before the first iteration (d_tol is +inf/NaN or
@@ -196,6 +199,11 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
     if (need_ls) {
         a.ls_slot[j] = s;
         a.ls_dest[j] = cont ? ns : -1;
+        // A trajectory whose last search rejected alpha = 1 will most likely reject it again: its first
+        // candidate is then evaluated together with the next three by the side-by-side kernel instead of
+        // being computed and written on its own (same candidates, same order, same result either way).
+        const bool side_by_side = !(a.flags & ILQR_FLAG_LS_SEQUENTIAL) && a.max_ls >= 2 && a.pred[id] != 0;
+        a.ls_from[j] = side_by_side ? 1 : 2;
         if (cont) a.idB[ns] = id;
     }
 }
@@ -220,7 +228,9 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_forward1_kernel(Pipe a)
     const int j = blockIdx.x * PIPE_WG + threadIdx.x;
     const int nls = a.cnt[1];
     bool need_bt = false;
-    if (j < nls) {
+    if (j < nls && a.ls_from[j] == 1) {
+        need_bt = true;         // handed to the side-by-side kernels untouched
+    } else if (j < nls) {
         const int s = a.ls_slot[j], dest = a.ls_dest[j], id = a.idA[s];
         const RecIn T = slot_T<M>(a.TA, a.cap, s);
         const Dest<M> d = make_dest<M>(a, dest, id);
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_forward1_kernel(Pipe a)
         if (complete || abandon) {
             if (!complete) copy_traj<M>(T, d, a.N - 1);    // search abandoned: the trajectory is kept (:69-72)
             record_search(a, id, 1, complete, Jn);
+            a.pred[id] = 0;
         } else {
             need_bt = true;
         }
@@ -274,7 +285,8 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_forward_level_kernel(Pipe a, con
 
 // ---------------------------------------------------------------- GL candidates per trajectory side by side
 // GL neighbouring lanes share one trajectory; lane g evaluates line-search
-// evaluation number first_ls + g (alpha = 0.5^(number - 1)), cost only.  The
+// evaluation number ls_from + g (alpha = 0.5^(number - 1)), cost only, where
+// ls_from is the entry's first evaluation not made yet.  The
 // search result is that of the first evaluation, in order, at which the
 // sequential loop would have stopped (:66-67); a ballot finds it and its
 // number and cost are left in win_ls / win_J for `commit`.  If none of the GL
@@ -284,7 +296,7 @@ template <class M, int GL, bool REPEAT>
 __global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_group_kernel(Pipe a, const int32_t* __restrict__ list_in,
                                                                        const int32_t* __restrict__ n_in,
                                                                        int32_t* __restrict__ list_out,
-                                                                       int32_t* __restrict__ n_out, int first_ls)
+                                                                       int32_t* __restrict__ n_out)
 {
     static_assert(64 % GL == 0, "whole groups per wavefront");
     constexpr int PER_WAVE = 64 / GL;
@@ -292,18 +304,19 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_group_kernel(Pipe a, c
     const int grp = lane / GL, g = lane % GL;
     const int q = blockIdx.x * PER_WAVE + grp;
     const bool live = q < *n_in;
-    int j = 0, s = 0;
+    int j = 0, s = 0, first_ls = 0;
     double J = 0.0, deltaJ = 0.0;
     if (live) {
         j = list_in[q];
         s = a.ls_slot[j];
+        first_ls = a.ls_from[j];
         J = a.J[a.idA[s]];
         deltaJ = a.dJ[s];
     }
     const ParCache<M> par(a.par);
     const unsigned long long gmask = ((GL >= 64) ? ~0ull : ((1ull << GL) - 1ull)) << (grp * GL);
     bool pending = live;
-    for (int base = first_ls; __ballot(pending) != 0ull; base += GL) {
+    for (int base = first_ls; __ballot(pending) != 0ull; base += GL) {     // base differs between groups
         const int ls = base + g;
         bool stop = false, complete = false;
         double Jn = 0.0;
@@ -326,7 +339,10 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_group_kernel(Pipe a, c
     }
     if (!REPEAT) {
         const int o = wave_append(pending && g == 0, n_out);
-        if (pending && g == 0) list_out[o] = j;
+        if (pending && g == 0) {
+            list_out[o] = j;
+            a.ls_from[j] = first_ls + GL;
+        }
     }
 }
 
@@ -355,6 +371,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_commit_kernel(Pipe a, const int3
         copy_traj<M>(T, d, a.N - 1);
     }
     record_search(a, id, ls, complete, a.win_J[j]);
+    a.pred[id] = (complete && ls == 1) ? 0 : 1;
 }
 
 }  // namespace ilqr

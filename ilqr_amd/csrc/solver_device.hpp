@@ -637,7 +637,7 @@ template <class M>
 struct Rec {
     static constexpr int nx = M::NX, m = M::NU, n = M::NDX;
     static constexpr int RT = (nx + m + 7) / 8 * 8;
-    static constexpr int RG = (m + m * n + 7) / 8 * 8;
+    static constexpr int RG = (m + m * n + 1) / 2 * 2;
 };
 
 struct RecIn {
