@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libilqr_hip.so")
+LIB_PATH = os.environ.get("ILQR_HIP_LIB") or os.path.join(_HERE, "lib", "libilqr_hip.so")   # override: A/B builds
 
 MODEL_CAR, MODEL_ACROBOT, MODEL_QUAD_EA, MODEL_QUAD_QUAT = 0, 1, 2, 3
 EXIT_DTOL, EXIT_SMALL_DELTAJ, EXIT_MAXITER, EXIT_LINALG = 0, 1, 2, 3
@@ -18,6 +18,7 @@ EXIT_NAMES = {0: "d_tol", 1: "deltaJ<1", 2: "max_iter", 3: "linalg_error"}
 FLAG_PARALLEL_LS = 1
 FLAG_LS_SEQUENTIAL = 2
 FLAG_TIMING = 4
+FLAG_SINGLE_STREAM = 8
 PHASES = ("init", "backward", "forward1", "backtrack", "commit")
 
 EXPORTS = ("ilqr_model_info", "ilqr_workspace_bytes", "ilqr_solve_batch", "ilqr_rollout_cost",

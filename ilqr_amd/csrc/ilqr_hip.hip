@@ -4,8 +4,12 @@
 // The batched solve is a pipeline of per-iteration kernels (solve_pipeline.hpp).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ilqr_hip.h"
@@ -164,7 +168,7 @@ WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
     w.bt = take(cap * 4); w.bt2 = take(cap * 4);
     w.ls_from = take(cap * 4); w.pred = take(cap * 4);
     w.win_ls = take(cap * 4); w.win_J = take(cap * 8);
-    w.cnt = take(64 * 4);
+    w.cnt = take(64 * 4 * 4);      // one block of counters per part (MAX_PARTS)
     w.total = off;
     return w;
 }
@@ -172,7 +176,7 @@ WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
 // ILQR_FLAG_TIMING: a pair of events around every launch, summed per phase when the solve is over.
 thread_local ilqr_timing g_timing;
 thread_local bool g_timing_valid = false;
-thread_local std::vector<hipEvent_t> g_events;
+thread_local std::vector<hipEvent_t> g_events;     // per host thread: each part of a solve is driven by its own thread
 
 struct PhaseTimer {
     bool on;
@@ -197,57 +201,30 @@ struct PhaseTimer {
         (void)hipEventRecord(g_events[used + 1], st);
         used += 2;
     }
-    int finish(int iterations)
+    int finish(int iterations, ilqr_timing* dst)
     {
-        if (!on) return ILQR_OK;
+        if (dst) memset(dst, 0, sizeof(*dst));
+        if (dst) dst->iterations = iterations;
+        if (!on || !dst) return ILQR_OK;
         HIP_TRY(hipStreamSynchronize(st));
-        memset(&g_timing, 0, sizeof(g_timing));
         for (size_t i = 0; i < phase.size() && 2 * i + 1 < used + 1; ++i) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, g_events[2 * i], g_events[2 * i + 1]));
-            g_timing.ms[phase[i]] += ms;
-            g_timing.launches[phase[i]] += 1;
+            dst->ms[phase[i]] += ms;
+            dst->launches[phase[i]] += 1;
         }
-        g_timing.iterations = iterations;
-        g_timing_valid = true;
         return ILQR_OK;
     }
 };
 
 inline unsigned blocks_for(long n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
-// run_ilqr for the whole batch: see solve_pipeline.hpp.  Blocks the calling thread on `stream`
-// twice per solver iteration to size the next launches (a few bytes read back).
+// One part of the batch (a contiguous range of trajectories with its own slots, lists and counters) from the
+// initial rollout to the last iteration, on one stream.  Blocks the calling thread on `st` twice per solver
+// iteration to size the next launches (a few bytes read back).
 template <class M>
-int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, const ilqr_outputs* out, char* ws,
-                 const WsLayout& w, hipStream_t st)
+int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
 {
-    static_assert(Rec<M>::RT == (M::NX + M::NU + 7) / 8 * 8 && Rec<M>::RG == (M::NU + M::NU * M::NDX + 1) / 2 * 2, "");
-    Pipe a;
-    memset(&a, 0, sizeof(a));
-    a.N = p->N; a.max_iter = p->max_iter; a.max_ls = p->max_ls; a.trace_len = p->trace_len; a.flags = p->flags;
-    a.d_tol = p->d_tol; a.B = p->B; a.cap = p->stride; a.par = p->params;
-    a.x0 = x0; a.u = u; a.x = x;
-    ilqr_outputs o;
-    if (out) o = *out; else memset(&o, 0, sizeof(o));
-    a.J0 = o.J0 ? o.J0 : (double*)(ws + w.J0);
-    a.J = o.J ? o.J : (double*)(ws + w.J);
-    a.dmax = o.dmax ? o.dmax : (double*)(ws + w.dmax);
-    a.maxq = o.max_abs_q ? o.max_abs_q : (double*)(ws + w.maxq);
-    a.iters = o.iters ? o.iters : (int32_t*)(ws + w.iters);
-    a.status = o.status ? o.status : (int32_t*)(ws + w.status);
-    a.regu_rounds = o.regu_rounds ? o.regu_rounds : (int32_t*)(ws + w.regu_rounds);
-    a.regu_stages = o.regu_stages ? o.regu_stages : (int32_t*)(ws + w.regu_stages);
-    a.ls_total = o.ls_total ? o.ls_total : (int32_t*)(ws + w.ls_total);
-    a.tr_ls = o.ls_evals; a.tr_acc = o.accepted; a.tr_J = o.J_trace; a.tr_dJ = o.deltaJ_trace;
-    a.TA = (double*)(ws + w.TA); a.TB = (double*)(ws + w.TB); a.G = (double*)(ws + w.G); a.Gscratch = (double*)(ws + w.Gscratch); a.dJ = (double*)(ws + w.dJ);
-    a.idA = (int32_t*)(ws + w.idA); a.idB = (int32_t*)(ws + w.idB);
-    a.ls_slot = (int32_t*)(ws + w.ls_slot); a.ls_dest = (int32_t*)(ws + w.ls_dest);
-    a.bt = (int32_t*)(ws + w.bt); a.bt2 = (int32_t*)(ws + w.bt2);
-    a.ls_from = (int32_t*)(ws + w.ls_from); a.pred = (int32_t*)(ws + w.pred);
-    a.win_ls = (int32_t*)(ws + w.win_ls); a.win_J = (double*)(ws + w.win_J);
-    a.cnt = (int32_t*)(ws + w.cnt);
-
     PhaseTimer tm((a.flags & ILQR_FLAG_TIMING) != 0, st);
     tm.begin(ILQR_PHASE_INIT);
     hipLaunchKernelGGL(pipe_init_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
@@ -258,7 +235,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
         const int status = !(INFINITY > a.d_tol) ? ILQR_EXIT_DTOL : ILQR_EXIT_MAXITER;
         hipLaunchKernelGGL(pipe_finish_all_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a, status);
         HIP_TRY(hipGetLastError());
-        return tm.finish(0);
+        return tm.finish(0, tout);
     }
     // Line-search schedule after evaluation 1 (all three give bit-identical results):
     //   default                  evaluations 2..5 four lanes per trajectory, then 6.. sixteen at a time, commit
@@ -336,7 +313,131 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
         int32_t* ti = a.idA; a.idA = a.idB; a.idB = ti;
         count = next;
     }
-    return tm.finish(iters_run);
+    return tm.finish(iters_run, tout);
+}
+
+// The same pipe restricted to trajectories [lo, lo + n): every per-trajectory and per-slot pointer moves by lo.
+template <class M>
+Pipe part_of(Pipe a, long lo, long n, int part)
+{
+    a.B = n;
+    a.x0 += lo; a.u += lo; a.x += lo;
+    a.J0 += lo; a.J += lo; a.dmax += lo; a.maxq += lo;
+    a.iters += lo; a.status += lo; a.regu_rounds += lo; a.regu_stages += lo; a.ls_total += lo;
+    if (a.tr_ls) a.tr_ls += lo;
+    if (a.tr_acc) a.tr_acc += lo;
+    if (a.tr_J) a.tr_J += lo;
+    if (a.tr_dJ) a.tr_dJ += lo;
+    a.TA += lo * Rec<M>::RT; a.TB += lo * Rec<M>::RT; a.G += lo * Rec<M>::RG; a.dJ += lo;
+    a.idA += lo; a.idB += lo; a.ls_slot += lo; a.ls_dest += lo; a.bt += lo; a.bt2 += lo;
+    a.ls_from += lo; a.pred += lo; a.win_ls += lo; a.win_J += lo;
+    a.cnt += 64 * part;
+    return a;
+}
+
+constexpr int MAX_PARTS = 4;
+thread_local std::map<int, std::vector<hipStream_t>> g_part_streams;    // per calling thread and device
+
+int parts_for(const ilqr_problem* p)
+{
+    if (p->flags & ILQR_FLAG_SINGLE_STREAM) return 1;
+    int want = 3;
+    if (const char* e = getenv("ILQR_HIP_PARTS")) want = atoi(e);
+    if (want < 1) want = 1;
+    if (want > MAX_PARTS) want = MAX_PARTS;
+    while (want > 1 && p->B / want < 16384) --want;      // a part should still fill the GPU in the first iterations
+    return want;
+}
+
+// run_ilqr for the whole batch: see solve_pipeline.hpp.  A large batch is cut into parts that run the whole
+// pipeline independently, each on its own stream and driven by its own host thread: trajectories never
+// interact, and while one part is in a compute-bound phase (backward pass) another is in a memory-bound one
+// (line search), or waiting for its host thread.  Work on `st` before the call is waited for, and `st` waits
+// for all parts before anything enqueued after the call runs.
+template <class M>
+int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, const ilqr_outputs* out, char* ws,
+                 const WsLayout& w, hipStream_t st)
+{
+    static_assert(Rec<M>::RT == (M::NX + M::NU + 7) / 8 * 8 && Rec<M>::RG == (M::NU + M::NU * M::NDX + 1) / 2 * 2, "");
+    Pipe a;
+    memset(&a, 0, sizeof(a));
+    a.N = p->N; a.max_iter = p->max_iter; a.max_ls = p->max_ls; a.trace_len = p->trace_len; a.flags = p->flags;
+    a.d_tol = p->d_tol; a.B = p->B; a.cap = p->stride; a.par = p->params;
+    a.x0 = x0; a.u = u; a.x = x;
+    ilqr_outputs o;
+    if (out) o = *out; else memset(&o, 0, sizeof(o));
+    a.J0 = o.J0 ? o.J0 : (double*)(ws + w.J0);
+    a.J = o.J ? o.J : (double*)(ws + w.J);
+    a.dmax = o.dmax ? o.dmax : (double*)(ws + w.dmax);
+    a.maxq = o.max_abs_q ? o.max_abs_q : (double*)(ws + w.maxq);
+    a.iters = o.iters ? o.iters : (int32_t*)(ws + w.iters);
+    a.status = o.status ? o.status : (int32_t*)(ws + w.status);
+    a.regu_rounds = o.regu_rounds ? o.regu_rounds : (int32_t*)(ws + w.regu_rounds);
+    a.regu_stages = o.regu_stages ? o.regu_stages : (int32_t*)(ws + w.regu_stages);
+    a.ls_total = o.ls_total ? o.ls_total : (int32_t*)(ws + w.ls_total);
+    a.tr_ls = o.ls_evals; a.tr_acc = o.accepted; a.tr_J = o.J_trace; a.tr_dJ = o.deltaJ_trace;
+    a.TA = (double*)(ws + w.TA); a.TB = (double*)(ws + w.TB); a.G = (double*)(ws + w.G); a.Gscratch = (double*)(ws + w.Gscratch); a.dJ = (double*)(ws + w.dJ);
+    a.idA = (int32_t*)(ws + w.idA); a.idB = (int32_t*)(ws + w.idB);
+    a.ls_slot = (int32_t*)(ws + w.ls_slot); a.ls_dest = (int32_t*)(ws + w.ls_dest);
+    a.bt = (int32_t*)(ws + w.bt); a.bt2 = (int32_t*)(ws + w.bt2);
+    a.ls_from = (int32_t*)(ws + w.ls_from); a.pred = (int32_t*)(ws + w.pred);
+    a.win_ls = (int32_t*)(ws + w.win_ls); a.win_J = (double*)(ws + w.win_J);
+    a.cnt = (int32_t*)(ws + w.cnt);
+
+    const bool timing = (a.flags & ILQR_FLAG_TIMING) != 0;
+    const int K = parts_for(p);
+    ilqr_timing total;
+    memset(&total, 0, sizeof(total));
+    if (K == 1) {
+        const int rc = run_part<M>(a, st, &total);
+        if (rc == ILQR_OK && timing) { g_timing = total; g_timing_valid = true; }
+        return rc;
+    }
+
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::vector<hipStream_t>& streams = g_part_streams[dev];
+    while ((int)streams.size() < K) {
+        hipStream_t s2;
+        HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        streams.push_back(s2);
+    }
+    hipEvent_t start;
+    HIP_TRY(hipEventCreateWithFlags(&start, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(start, st));
+    for (int k = 0; k < K; ++k) HIP_TRY(hipStreamWaitEvent(streams[k], start, 0));
+
+    std::vector<int> rcs(K, ILQR_OK);
+    std::vector<std::string> msgs(K);
+    std::vector<ilqr_timing> tms(K);
+    auto work = [&](int k) {
+        if (hipSetDevice(dev) != hipSuccess) { rcs[k] = ILQR_E_HIP; msgs[k] = "hipSetDevice failed in a part's thread"; return; }
+        const long lo = ((a.B * k / K) + 63) / 64 * 64, hi = (k + 1 == K) ? a.B : ((a.B * (k + 1) / K) + 63) / 64 * 64;
+        rcs[k] = run_part<M>(part_of<M>(a, lo, hi - lo, k), streams[k], &tms[k]);
+        if (rcs[k] != ILQR_OK) msgs[k] = g_err;
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < K; ++k) threads.emplace_back(work, k);
+    work(0);
+    for (auto& t : threads) t.join();
+
+    int rc = ILQR_OK;
+    for (int k = 0; k < K; ++k) {
+        hipEvent_t done;
+        HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(done, streams[k]));
+        HIP_TRY(hipStreamWaitEvent(st, done, 0));
+        HIP_TRY(hipEventDestroy(done));
+        if (rcs[k] != ILQR_OK && rc == ILQR_OK) rc = fail(rcs[k], "%s", msgs[k].c_str());
+        for (int ph = 0; ph < ILQR_PHASE_COUNT; ++ph) {
+            total.ms[ph] += tms[k].ms[ph];
+            total.launches[ph] += tms[k].launches[ph];
+        }
+        if (tms[k].iterations > total.iterations) total.iterations = tms[k].iterations;
+    }
+    HIP_TRY(hipEventDestroy(start));
+    if (rc == ILQR_OK && timing) { g_timing = total; g_timing_valid = true; }
+    return rc;
 }
 
 template <class F>

@@ -39,7 +39,10 @@ struct CarModel {
     static constexpr bool UNROLL = true;
     // waves per SIMD the backward kernel is built for: the stage's matrices need ~220 registers per lane, and
     // asking for 3 or 4 waves makes the compiler spill ~1 KB per lane (measured slower than 2 resident waves)
-    static constexpr int BACKWARD_WAVES = 1;
+#ifndef ILQR_CAR_BW
+#define ILQR_CAR_BW 1
+#endif
+    static constexpr int BACKWARD_WAVES = ILQR_CAR_BW;
     __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
     {
         car_gen_dynamics(par, x, u, xn);

@@ -40,6 +40,10 @@
 
 namespace ilqr {
 
+#ifndef ILQR_FWD_WAVES
+#define ILQR_FWD_WAVES 1
+#endif
+constexpr int FWD_WAVES = ILQR_FWD_WAVES;   // waves per SIMD the forward-pass kernels are built for
 constexpr int PIPE_WG = 64;      // one wavefront per workgroup: backward_stage exchanges data between lanes without barriers
 static_assert(PIPE_WG == 64, "backward_stage assumes single-wavefront workgroups");
 
@@ -223,7 +227,7 @@ __device__ __forceinline__ void record_search(const Pipe& a, int id, int ls, boo
 
 // ---------------------------------------------------------------- forward, alpha = 1
 template <class M>
-__global__ __launch_bounds__(PIPE_WG) void pipe_forward1_kernel(Pipe a)
+__global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward1_kernel(Pipe a)
 {
     const int j = blockIdx.x * PIPE_WG + threadIdx.x;
     const int nls = a.cnt[1];
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_forward1_kernel(Pipe a)
 // written; entries whose search goes on are appended to `list_out`.  (The
 // strictly sequential schedule, ILQR_FLAG_LS_SEQUENTIAL.)
 template <class M>
-__global__ __launch_bounds__(PIPE_WG) void pipe_forward_level_kernel(Pipe a, const int32_t* __restrict__ list_in,
+__global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward_level_kernel(Pipe a, const int32_t* __restrict__ list_in,
                                                                      const int32_t* __restrict__ n_in,
                                                                      int32_t* __restrict__ list_out,
                                                                      int32_t* __restrict__ n_out, int ls, double alpha)
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_forward_level_kernel(Pipe a, con
 // stops: with REPEAT the same lanes go on with the next GL numbers (the last
 // number, max_ls, always stops), otherwise the entry is appended to list_out.
 template <class M, int GL, bool REPEAT>
-__global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_group_kernel(Pipe a, const int32_t* __restrict__ list_in,
+__global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_backtrack_group_kernel(Pipe a, const int32_t* __restrict__ list_in,
                                                                        const int32_t* __restrict__ n_in,
                                                                        int32_t* __restrict__ list_out,
                                                                        int32_t* __restrict__ n_out)
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backtrack_group_kernel(Pipe a, c
 // rejected: the accepted candidate is recomputed and written, or, when the
 // search was abandoned, the trajectory is carried over unchanged (:69-72).
 template <class M>
-__global__ __launch_bounds__(PIPE_WG) void pipe_commit_kernel(Pipe a, const int32_t* __restrict__ list_in,
+__global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_commit_kernel(Pipe a, const int32_t* __restrict__ list_in,
                                                               const int32_t* __restrict__ n_in)
 {
     const int q = blockIdx.x * PIPE_WG + threadIdx.x;

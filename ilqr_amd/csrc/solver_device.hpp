@@ -266,19 +266,18 @@ template <int w, int UF>
 __device__ inline int has_negative_eig_packed(double* L, double& maxq)
 {
     constexpr int NL = w * (w + 1) / 2;
-    bool finite = true;
     double mq = maxq;
+    double poison = 0.0;    // 0 * entry summed up: stays 0 unless an entry is an infinity or a NaN
     double acc[w];      // |Q_jj| + sum_k |l_jk^2 d_k|: the size of the terms pivot j is the difference of
     ILQR_UNROLL
     for (int e = 0; e < NL; ++e) {
-        const double a = fabs(L[e]);
-        finite = finite && (a <= DBL_MAX);
-        mq = (a > mq) ? a : mq;
+        mq = fmax(mq, fabs(L[e]));          // a NaN entry never wins, as in a chain of `a > mq` comparisons
+        poison = __builtin_fma(0.0, L[e], poison);
     }
     ILQR_UNROLL
     for (int i = 0; i < w; ++i) acc[i] = fabs(L[tri(i, i)]);
     maxq = mq;
-    if (!finite) return -1;
+    if (poison != poison) return -1;
     int result = 0;
     bool done = false;
     ILQR_UNROLL
@@ -319,11 +318,10 @@ __device__ inline int has_negative_eig_packed(double* L, double& maxq)
 // Regularisation loop of iLQRController.py:106-115,
 //     regu = 0.1; while any(eigvals(Q) < 0): Q += (regu [fx fu])'[fx fu]; regu *= 2
 // Because regu is 0.1 times a power of two, the update of round r is exactly
-// 2^r * P with P = (0.1 [fx fu])'[fx fu] evaluated once, so "after r rounds" is a
-// matrix Q(r) any lane can build:
-//   r <= REGU_EXACT : Q(r) = Q(r-1) + 2^(r-1) P, accumulated one by one as the reference does;
-//   r >  REGU_EXACT : Q(r) = Q(REGU_EXACT) + (2^r - 2^REGU_EXACT) P, the same sum up to rounding
-//                     (only ill-conditioned solves need more than ~8 rounds).
+// 2^r * P with P = (0.1 [fx fu])'[fx fu] evaluated once, so "after r rounds" is
+//     Q(r) = Q + (2^r - 1) P,
+// the reference's running sum up to the rounding of its r additions, and a
+// matrix any lane can build with one fused multiply-add per entry.
 // The result of the loop is the first r = 0, 1, 2, ... whose Q(r) has no negative eigenvalue.
 //
 // Execution.  Typically a few lanes of a wavefront need 1-8 rounds at a stage
@@ -336,17 +334,19 @@ __device__ inline int has_negative_eig_packed(double* L, double& maxq)
 //     Q(REGU_BASE) and P; lane l tests Q(REGU_BASE + 1 + l), then +64, ...
 // ------------------------------------------------------------------
 constexpr int REGU_BASE = 8;      // rounds covered by the group scan (or lane by lane for the big plants)
-constexpr int REGU_EXACT = 12;    // rounds accumulated one by one
 constexpr int REGU_GROUPS = 8;    // trajectories per group scan; REGU_GROUPS * REGU_BASE == 64
+
+// 2^r - 1, the factor of P after r rounds (exact up to r = 53, then 2^r)
+__device__ __forceinline__ double regu_coef(int r) { return ldexp(1.0, r) - 1.0; }
 
 template <int n, int m>
 struct QPack {
     static constexpr int w = n + m;
     static constexpr int NL = w * (w + 1) / 2;
     static constexpr bool GROUP_SCAN = NL <= 36;
-    // per-wavefront LDS: Q and P of up to REGU_GROUPS trajectories, then one {test result, max|Q|} pair per lane
-    static constexpr int RES = (GROUP_SCAN ? REGU_GROUPS : 1) * 2 * NL;
-    static constexpr int LDS_DOUBLES = RES + 128;
+    // per-wavefront LDS, in doubles: Q and P of up to REGU_GROUPS trajectories (small Hessians) or of the one
+    // trajectory being scanned (big ones)
+    static constexpr int LDS_DOUBLES = (GROUP_SCAN ? REGU_GROUPS : 1) * 2 * NL;
 };
 
 // ------------------------------------------------------------------
@@ -370,27 +370,28 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
     double Qx[n], Qu[m], QL[NL], aux[TR::AUX];
     TR::backward_terms(par, xk, uk, Vx, VL, Qx, Qu, QL, aux);
 
-    // ---- regularisation: round 0 test in every lane
     bool ok = true;
     int r = 0;
-    bool need;
-    {
-        double L[NL];
-        ILQR_UNROLL
-        for (int e = 0; e < NL; ++e) L[e] = QL[e];
-        const int neg = has_negative_eig_packed<w, UF>(L, maxq);
-        ok = ok && (neg >= 0);
-        need = alive && (neg == 1);
-    }
-    if (need) regu_stages += 1;
     const int lane = threadIdx.x & 63;
-    double* const res = lds + QPack<n, m>::RES;          // [64][2]
-    bool stuck_here = false;
-
     if constexpr (QPack<n, m>::GROUP_SCAN) {
+        // ---- small Hessians: round-0 test on a copy in every lane, then the wavefront scans
+        double* const ldsP = lds + REGU_GROUPS * NL;                     // P of the published trajectories
+        bool need;
+        {
+            double L[NL];
+            ILQR_UNROLL
+            for (int e = 0; e < NL; ++e) L[e] = QL[e];
+            const int neg = has_negative_eig_packed<w, UF>(L, maxq);
+            ok = ok && (neg >= 0);
+            need = alive && (neg == 1);
+        }
+        if (need) regu_stages += 1;
+        bool stuck_here = false;
+
         // ---- group scan: rounds 1..REGU_BASE of up to REGU_GROUPS trajectories at once
         unsigned long long pend = __ballot(need);
         const unsigned long long below = (1ull << lane) - 1ull;
+        const int g = lane / REGU_BASE, c = lane % REGU_BASE;         // this lane tests trajectory g after c + 1 rounds
         while (pend) {
             const int rank = __popcll(pend & below);
             const bool src = need && rank < REGU_GROUPS;
@@ -401,150 +402,162 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
                 TR::regu_p(aux, PL);
                 ILQR_UNROLL
                 for (int e = 0; e < NL; ++e) {
-                    lds[rank * 2 * NL + e] = QL[e];
-                    lds[rank * 2 * NL + NL + e] = PL[e];
+                    lds[rank * NL + e] = QL[e];
+                    ldsP[rank * NL + e] = PL[e];
                 }
             }
             wave_sync();
-            const int g = lane / REGU_BASE, c = lane % REGU_BASE;     // trajectory g, c + 1 rounds
             int t = 1;
             double mq = 0.0;
             if (g < nsrc) {
                 double L[NL];
-                const double* const q = lds + g * 2 * NL;
+                const double coef = regu_coef(c + 1);
                 ILQR_UNROLL
-                for (int e = 0; e < NL; ++e) L[e] = q[e];
-                double pw = 1.0;
-#pragma unroll 1
-                for (int i = 0; i <= c; ++i) {
-                    ILQR_UNROLL
-                    for (int e = 0; e < NL; ++e) L[e] += pw * q[NL + e];
-                    pw *= 2.0;
-                }
+                for (int e = 0; e < NL; ++e) L[e] = __builtin_fma(coef, ldsP[g * NL + e], lds[g * NL + e]);
                 t = has_negative_eig_packed<w, UF>(L, mq);
             }
-            res[lane * 2] = (double)t;
-            res[lane * 2 + 1] = mq;
-            wave_sync();
+            // first passing round of every group, its verdict, and the largest |Q| met up to it
+            const unsigned long long passed = __ballot(t != 1);
+            ILQR_UNROLL
+            for (int dlt = 1; dlt < REGU_BASE; dlt *= 2) {
+                const double up = __shfl_up(mq, dlt, REGU_BASE);
+                if (c >= dlt) mq = fmax(mq, up);
+            }
+            const int byte = (int)((passed >> (REGU_BASE * (src ? rank : 0))) & ((1u << REGU_BASE) - 1u));
+            const int cstar = byte ? __ffs(byte) - 1 : -1;
+            const int from = (src ? rank : 0) * REGU_BASE + (cstar >= 0 ? cstar : REGU_BASE - 1);
+            const int tt = __shfl(t, from);
+            const double mqs = __shfl(mq, from);
             if (src) {
-                int cstar = -1, tt = 1;
-                double mqs = maxq;
-#pragma unroll 1
-                for (int c2 = 0; c2 < REGU_BASE; ++c2)
-                    if (cstar < 0) {
-                        tt = (int)res[(rank * REGU_BASE + c2) * 2];
-                        const double q2 = res[(rank * REGU_BASE + c2) * 2 + 1];
-                        mqs = (q2 > mqs) ? q2 : mqs;
-                        if (tt != 1) cstar = c2;
-                    }
-                maxq = mqs;
+                maxq = fmax(maxq, mqs);
                 r = (cstar >= 0) ? cstar + 1 : REGU_BASE;
-                double PL[NL];
-                TR::regu_p(aux, PL);
-                double pw = 1.0;
-#pragma unroll 1
-                for (int i = 0; i < r; ++i) {
+                if (cstar >= 0) {
+                    const double coef = regu_coef(r);
                     ILQR_UNROLL
-                    for (int e = 0; e < NL; ++e) QL[e] += pw * PL[e];
-                    pw *= 2.0;
+                    for (int e = 0; e < NL; ++e) QL[e] = __builtin_fma(coef, ldsP[rank * NL + e], QL[e]);
+                    ok = ok && (tt >= 0);
+                } else {
+                    stuck_here = true;
                 }
-                if (cstar >= 0) ok = ok && (tt >= 0);
-                else stuck_here = true;
                 need = false;
             }
             pend &= ~__ballot(src);
         }
+
+        // ---- stuck scan: rounds REGU_BASE + 1, + 2, ... of one trajectory, 64 at a time
+        unsigned long long stuck = __ballot(stuck_here);
+        while (stuck) {
+            const int src = __ffsll((long long)stuck) - 1;
+            stuck &= stuck - 1;
+            wave_sync();
+            if (lane == src) {
+                double PL[NL];
+                TR::regu_p(aux, PL);
+                ILQR_UNROLL
+                for (int e = 0; e < NL; ++e) {
+                    lds[e] = QL[e];
+                    ldsP[e] = PL[e];
+                }
+            }
+            wave_sync();
+            for (int base = REGU_BASE + 1;; base += 64) {
+                const int rc = base + lane;
+                const double coef = regu_coef(rc);
+                double L[NL];
+                ILQR_UNROLL
+                for (int e = 0; e < NL; ++e) L[e] = __builtin_fma(coef, ldsP[e], lds[e]);
+                double mq = 0.0;
+                const int t = has_negative_eig_packed<w, UF>(L, mq);
+                const unsigned long long stops = __ballot(t != 1);
+                if (stops) {
+                    const int win = __ffsll((long long)stops) - 1;
+                    const int tw = __shfl(t, win);
+                    const double mqw = __shfl(mq, win);
+                    if (lane == src) {
+                        r = base + win;
+                        const double cw = regu_coef(r);
+                        ILQR_UNROLL
+                        for (int e = 0; e < NL; ++e) QL[e] = __builtin_fma(cw, ldsP[e], QL[e]);
+                        ok = ok && (tw >= 0);
+                        maxq = fmax(maxq, mqw);
+                    }
+                    break;
+                }
+                if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
+                    if (lane == src) ok = false;
+                    break;
+                }
+            }
+        }
     } else {
-        // ---- big plants: rounds 1..REGU_BASE lane by lane
+        // ---- big Hessians: round-0 test on a copy, rounds 1..REGU_BASE lane by lane, then the stuck scan
+        bool need;
+        {
+            double L[NL];
+            for (int e = 0; e < NL; ++e) L[e] = QL[e];
+            const int neg = has_negative_eig_packed<w, UF>(L, maxq);
+            ok = ok && (neg >= 0);
+            need = alive && (neg == 1);
+        }
+        if (need) regu_stages += 1;
+        bool stuck_here = false;
         if (need) {
             double PL[NL];
             TR::regu_p(aux, PL);
-            double pw = 1.0;
             while (need && r < REGU_BASE) {
-                for (int e = 0; e < NL; ++e) QL[e] += pw * PL[e];
-                pw *= 2.0;
                 r += 1;
+                const double coef = regu_coef(r);
                 double L[NL];
-                for (int e = 0; e < NL; ++e) L[e] = QL[e];
+                for (int e = 0; e < NL; ++e) L[e] = __builtin_fma(coef, PL[e], QL[e]);
                 const int neg = has_negative_eig_packed<w, UF>(L, maxq);
                 ok = ok && (neg >= 0);
                 need = (neg == 1);
             }
+            if (!need) {
+                const double coef = regu_coef(r);
+                for (int e = 0; e < NL; ++e) QL[e] = __builtin_fma(coef, PL[e], QL[e]);
+            }
             stuck_here = need;
         }
-    }
-
-    // ---- stuck scan: rounds REGU_BASE + 1, + 2, ... of one trajectory, 64 at a time
-    unsigned long long stuck = __ballot(stuck_here);
-    while (stuck) {
-        const int src = __ffsll((long long)stuck) - 1;
-        stuck &= stuck - 1;
-        wave_sync();
-        if (lane == src) {
-            double PL[NL];
-            TR::regu_p(aux, PL);
-            for (int e = 0; e < NL; ++e) {
-                lds[e] = QL[e];
-                lds[NL + e] = PL[e];
-            }
-        }
-        wave_sync();
-        for (int base = REGU_BASE + 1;; base += 64) {
-            const int rc = base + lane;
-            const double coef = ldexp(1.0, rc) - ldexp(1.0, REGU_EXACT);
-            double L[NL];
-            ILQR_UNROLL
-            for (int e = 0; e < NL; ++e) L[e] = lds[e];
-            double pw = (double)(1 << REGU_BASE);
-#pragma unroll 1
-            for (int i = REGU_BASE; i < REGU_EXACT; ++i) {
-                if (i < rc) {
-                    ILQR_UNROLL
-                    for (int e = 0; e < NL; ++e) L[e] += pw * lds[NL + e];
+        unsigned long long stuck = __ballot(stuck_here);
+        while (stuck) {
+            const int src = __ffsll((long long)stuck) - 1;
+            stuck &= stuck - 1;
+            wave_sync();
+            if (lane == src) {
+                double PL[NL];
+                TR::regu_p(aux, PL);
+                for (int e = 0; e < NL; ++e) {
+                    lds[e] = QL[e];
+                    lds[NL + e] = PL[e];
                 }
-                pw *= 2.0;
             }
-            if (rc > REGU_EXACT) {
-                ILQR_UNROLL
-                for (int e = 0; e < NL; ++e) L[e] = __dadd_rn(L[e], __dmul_rn(coef, lds[NL + e]));
-            }
-            double mq = 0.0;
-            const int t = has_negative_eig_packed<w, UF>(L, mq);
-            const unsigned long long stops = __ballot(t != 1);
-            if (stops) {
-                const int win = __ffsll((long long)stops) - 1;
-                if (lane == win) {
-                    res[0] = (double)t;
-                    res[1] = mq;
-                }
-                wave_sync();
-                if (lane == src) {
-                    const int rw = base + win;
-                    const double cw = ldexp(1.0, rw) - ldexp(1.0, REGU_EXACT);
-                    double PL[NL];
-                    TR::regu_p(aux, PL);
-                    double pw2 = (double)(1 << REGU_BASE);
-#pragma unroll 1
-                    for (int i = REGU_BASE; i < REGU_EXACT; ++i) {
-                        if (i < rw) {
-                            ILQR_UNROLL
-                            for (int e = 0; e < NL; ++e) QL[e] += pw2 * PL[e];
-                        }
-                        pw2 *= 2.0;
+            wave_sync();
+            for (int base = REGU_BASE + 1;; base += 64) {
+                const int rc = base + lane;
+                const double coef = regu_coef(rc);
+                double L[NL];
+                for (int e = 0; e < NL; ++e) L[e] = __builtin_fma(coef, lds[NL + e], lds[e]);
+                double mq = 0.0;
+                const int t = has_negative_eig_packed<w, UF>(L, mq);
+                const unsigned long long stops = __ballot(t != 1);
+                if (stops) {
+                    const int win = __ffsll((long long)stops) - 1;
+                    const int tw = __shfl(t, win);
+                    const double mqw = __shfl(mq, win);
+                    if (lane == src) {
+                        r = base + win;
+                        const double cw = regu_coef(r);
+                        for (int e = 0; e < NL; ++e) QL[e] = __builtin_fma(cw, lds[NL + e], QL[e]);
+                        ok = ok && (tw >= 0);
+                        maxq = fmax(maxq, mqw);
                     }
-                    if (rw > REGU_EXACT) {
-                        ILQR_UNROLL
-                        for (int e = 0; e < NL; ++e) QL[e] = __dadd_rn(QL[e], __dmul_rn(cw, PL[e]));
-                    }
-                    ok = ok && (res[0] >= 0.0);
-                    r = rw;
-                    maxq = (res[1] > maxq) ? res[1] : maxq;
+                    break;
                 }
-                break;
-            }
-            if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
-                if (lane == src) ok = false;
-                break;
+                if (base > 1200) {
+                    if (lane == src) ok = false;
+                    break;
+                }
             }
         }
     }

@@ -66,7 +66,9 @@ enum {
     ILQR_FLAG_NONE = 0,
     ILQR_FLAG_PARALLEL_LS = 1,   /* sixteen at a time right after alpha = 1 was rejected */
     ILQR_FLAG_LS_SEQUENTIAL = 2, /* never side by side: one launch per candidate (max_ls <= 60) */
-    ILQR_FLAG_TIMING = 4         /* bracket every kernel launch with HIP events: see ilqr_last_timing() */
+    ILQR_FLAG_TIMING = 4,        /* bracket every kernel launch with HIP events: see ilqr_last_timing() */
+    ILQR_FLAG_SINGLE_STREAM = 8  /* run everything on the caller's stream (default: large batches are cut into
+                                    parts that run concurrently on internal streams, one host thread each) */
 };
 
 /* Kernel phases of ilqr_solve_batch, for ilqr_timing. */
@@ -120,8 +122,10 @@ size_t ilqr_workspace_bytes(const ilqr_problem *p);
  *   x0 [nx][stride]        in
  *   u  [N-1][nu][stride]   in: initial controls; out: optimised controls (in place, like :72)
  *   x  [N][nx][stride]     out: optimised states (:71, :84)
- * `stream` is a hipStream_t (NULL = default stream).  The call blocks: it waits on `stream`
- * a few times per solver iteration to read back how many trajectories are still running. */
+ * `stream` is a hipStream_t (NULL = default stream).  The call blocks: it waits on the GPU a few times per
+ * solver iteration to read back how many trajectories are still running.  Work enqueued on `stream` before
+ * the call is waited for, and work enqueued after it runs after the solve; a batch of 32768 or more is cut
+ * into parts that run on internal streams (see ILQR_FLAG_SINGLE_STREAM).  The result does not depend on that. */
 int ilqr_solve_batch(const ilqr_problem *p, const double *x0, double *u, double *x, const ilqr_outputs *out,
                      void *workspace, size_t workspace_bytes, void *stream);
 

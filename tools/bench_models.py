@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Throughput of the other plants at the configurations of the coverage contract (not the headline bench):
+acrobot N=100 B=65536, Euler quadrotor N=100, quaternion quadrotor N=80.  One line per plant."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from ilqr_amd.batch import BatchSolver
+from oracle import c_oracle as co
+
+
+def cfg(kind):
+    Q = np.diag([10.0] * 6 + [1.0] * 6); Qf = np.diag([500.0] * 3 + [100.0] * 3 + [20.0] * 6); R = np.diag([0.02] * 4)
+    if kind == "acrobot":
+        par = co.pack_quadratic(0.05, np.diag([1, 1, .1, .1]), 100.0 * np.eye(4), [[0.01]], [np.pi, 0, 0, 0], [0.0])
+        return 1, par, 100, 20, 10, 1e-3
+    if kind == "quad_ea":
+        xref = np.zeros(12); xref[2] = 1.0
+        return 2, co.pack_quadratic(0.01, Q, Qf, R, xref, np.zeros(4)), 100, 20, 10, 5e-4
+    xref = np.zeros(13); xref[0] = 1.0; xref[6] = 1.0
+    return 3, co.pack_quat(0.01, Q, Qf, R, xref, np.zeros(4)), 80, 20, 10, 5e-4
+
+
+def inputs(kind, rng, B, N):
+    if kind == "acrobot":
+        x0 = np.column_stack([rng.uniform(-np.pi, np.pi, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B),
+                              rng.uniform(-1, 1, B)])
+        return x0, rng.standard_normal((B, N - 1, 1))
+    if kind == "quad_ea":
+        x0 = np.zeros((B, 12)); x0[:, 2] = 0.8; x0[:, 3:6] = 0.5 * rng.standard_normal((B, 3))
+        return x0, 2.0 * rng.standard_normal((B, N - 1, 4))
+    x0 = np.zeros((B, 13)); x0[:, 6] = 0.8
+    q = np.column_stack([np.ones(B), 0.25 * rng.standard_normal((B, 3))])
+    x0[:, :4] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    return x0, 2.0 * rng.standard_normal((B, N - 1, 4))
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--kinds", default="acrobot,quad_ea,quad_quat")
+ap.add_argument("--batch", type=int, default=65536)
+ap.add_argument("--cpu", type=int, default=512)
+a = ap.parse_args()
+for kind in a.kinds.split(","):
+    mid, par, N, mi, ml, dt = cfg(kind)
+    B = a.batch
+    x0, u0 = inputs(kind, np.random.default_rng(2), B, N)
+    s = BatchSolver(mid, par, N, mi, ml, dt)
+    x0d = torch.as_tensor(x0).cuda().t().contiguous(); u_init = torch.as_tensor(u0).cuda().permute(1, 2, 0).contiguous()
+    u = u_init.clone(); x = torch.empty((N, x0.shape[1], B), dtype=torch.float64, device="cuda"); out = s.alloc_outputs(B)
+    for rep in range(2):
+        u.copy_(u_init); torch.cuda.synchronize(); t0 = time.perf_counter()
+        s.solve_soa(x0d, u, x, out); torch.cuda.synchronize(); dtm = time.perf_counter() - t0
+    st = torch.bincount(out["status"], minlength=4).cpu().tolist()
+    c = min(a.cpu, B)
+    t1 = time.perf_counter(); r = co.solve_batch(kind, par, N, mi, ml, dt, x0[:c], u0[:c]); tc = time.perf_counter() - t1
+    same = (out["iters"][:c].cpu().numpy() == r["info"]["iters"]).mean()
+    print(json.dumps(dict(model=kind, N=N, B=B, ms=1e3 * dtm, solves_per_s=B / dtm, mean_iters=float(out["iters"].double().mean()),
+                          exit=st, cpu_solves_per_s=c / tc, iters_identical_frac=float(same))), flush=True)
