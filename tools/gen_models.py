@@ -119,6 +119,21 @@ def emit_function(name, inputs, outputs, doc, pre=None):
     npre = len(pre)
     flat = [e for _, e in pre] + flat
     t0 = time.time()
+    # sin(a) and cos(a) of the same argument share one range reduction: both come from one ILQR_SINCOS
+    kinds = {}
+    for e in flat:
+        for node in sp.preorder_traversal(e):
+            if isinstance(node, (sp.sin, sp.cos)):
+                kinds.setdefault(node.args[0], set()).add(type(node))
+    pairs = [a for a, k in kinds.items() if k == {sp.sin, sp.cos} and not a.has(sp.sin, sp.cos, sp.tan)]
+    pairs.sort(key=str)
+    sc = {a: (sp.Symbol(f"sn{i}"), sp.Symbol(f"cs{i}")) for i, a in enumerate(pairs)}
+    if sc:
+        rep = {}
+        for a, (S, Cc) in sc.items():
+            rep[sp.sin(a)] = S
+            rep[sp.cos(a)] = Cc
+        flat = [e.xreplace(rep) for e in flat]
     repl, red = sp.cse(flat, symbols=sp.numbered_symbols("t"), optimizations="basic", order="none")
     lines = []
     args = ", ".join([f"const double* __restrict__ {n}" for n, _ in inputs] +
@@ -136,6 +151,10 @@ def emit_function(name, inputs, outputs, doc, pre=None):
     for n, syms in inputs:
         if not any(s in used for s in syms):
             lines.append(f"    (void){n};")
+    for a in pairs:
+        S, Cc = sc[a]
+        lines.append(f"    double {S}, {Cc};")
+        lines.append(f"    ILQR_SINCOS({_P.doprint(a.xreplace(sub))}, {S}, {Cc});")
     for t, e in repl:
         lines.append(f"    const double {t} = {_P.doprint(e.xreplace(sub))};")
     for k in range(npre):
@@ -149,6 +168,7 @@ def emit_function(name, inputs, outputs, doc, pre=None):
             k += 1
     lines.append("}")
     ops = _count_ops([e for _, e in repl] + red)
+    ops["sin"] += len(pairs); ops["cos"] += len(pairs); ops["flops"] += 2 * len(pairs)
     sys.stderr.write(f"  {name}: {len(repl)} temporaries, {ops['flops']} flops, cse {time.time() - t0:.1f}s\n")
     return "\n".join(lines) + "\n", ops
 
@@ -164,6 +184,14 @@ HEADER = """/* GENERATED by tools/gen_models.py -- do not edit.
 #    define ILQR_HD __host__ __device__
 #  else
 #    define ILQR_HD
+#  endif
+#endif
+/* sine and cosine of one argument: one shared range reduction on the GPU */
+#ifndef ILQR_SINCOS
+#  if defined(__HIP_DEVICE_COMPILE__)
+#    define ILQR_SINCOS(a, s, c) sincos((a), &(s), &(c))
+#  else
+#    define ILQR_SINCOS(a, s, c) ((s) = sin(a), (c) = cos(a))
 #  endif
 #endif
 
