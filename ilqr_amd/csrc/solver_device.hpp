@@ -300,7 +300,11 @@ __device__ inline int has_negative_eig_packed(double* L, double& maxq)
                     done = true;
                 }
             } else {
-                const double pinv = 1.0 / p;
+                // the factorisation only decides signs: a reciprocal refined to ~1 ulp is enough, and several
+                // times cheaper than an IEEE division
+                double pinv = __builtin_amdgcn_rcp(p);
+                pinv = __builtin_fma(__builtin_fma(-p, pinv, 1.0), pinv, pinv);
+                pinv = __builtin_fma(__builtin_fma(-p, pinv, 1.0), pinv, pinv);
                 ILQR_UNROLL
                 for (int i = j + 1; i < w; ++i) {
                     const double lij = L[tri(i, j)] * pinv;
