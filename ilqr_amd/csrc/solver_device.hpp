@@ -277,45 +277,37 @@ __device__ inline int has_negative_eig_packed(double* L, double& maxq)
     ILQR_UNROLL
     for (int i = 0; i < w; ++i) acc[i] = fabs(L[tri(i, i)]);
     maxq = mq;
-    if (poison != poison) return -1;
-    int result = 0;
-    bool done = false;
+    // Straight-line code, no early exit: once the verdict is in (`decided`) the remaining steps still run but
+    // can no longer change it; a skipped (zero) pivot eliminates nothing (pinv = 0).
+    bool negative = false;
     ILQR_UNROLL
     for (int j = 0; j < w; ++j) {
-        if (!done) {
-            const double p = L[tri(j, j)];
-            const double thr = PIVOT_TOL * acc[j];
-            if (p < -thr) {
-                result = 1;
-                done = true;
-            } else if (p <= thr) {
-                bool nz = false;
-                ILQR_UNROLL
-                for (int i = j + 1; i < w; ++i) {
-                    const double c = L[tri(i, j)];
-                    nz = nz || (c * c > 4.0 * thr * fabs(L[tri(i, i)]));
-                }
-                if (nz) {
-                    result = 1;
-                    done = true;
-                }
-            } else {
-                // the factorisation only decides signs: a reciprocal refined to ~1 ulp is enough, and several
-                // times cheaper than an IEEE division
-                double pinv = __builtin_amdgcn_rcp(p);
-                pinv = __builtin_fma(__builtin_fma(-p, pinv, 1.0), pinv, pinv);
-                pinv = __builtin_fma(__builtin_fma(-p, pinv, 1.0), pinv, pinv);
-                ILQR_UNROLL
-                for (int i = j + 1; i < w; ++i) {
-                    const double lij = L[tri(i, j)] * pinv;
-                    ILQR_UNROLL
-                    for (int k = j + 1; k <= i; ++k) L[tri(i, k)] -= lij * L[tri(k, j)];
-                    acc[i] += fabs(lij * L[tri(i, j)]);
-                }
-            }
+        const double p = L[tri(j, j)];
+        const double thr = PIVOT_TOL * acc[j];
+        const bool neg = p < -thr;
+        const bool zero = !neg && (p <= thr);
+        bool nz = false;
+        ILQR_UNROLL
+        for (int i = j + 1; i < w; ++i) {
+            const double c = L[tri(i, j)];
+            nz = nz || (c * c > 4.0 * thr * fabs(L[tri(i, i)]));
+        }
+        negative = negative || neg || (zero && nz);
+        // the factorisation only decides signs: a reciprocal refined to ~1 ulp is enough, and several times
+        // cheaper than an IEEE division
+        double pinv = __builtin_amdgcn_rcp(p);
+        pinv = __builtin_fma(__builtin_fma(-p, pinv, 1.0), pinv, pinv);
+        pinv = __builtin_fma(__builtin_fma(-p, pinv, 1.0), pinv, pinv);
+        pinv = (zero || negative) ? 0.0 : pinv;
+        ILQR_UNROLL
+        for (int i = j + 1; i < w; ++i) {
+            const double lij = L[tri(i, j)] * pinv;
+            ILQR_UNROLL
+            for (int k = j + 1; k <= i; ++k) L[tri(i, k)] -= lij * L[tri(k, j)];
+            acc[i] += fabs(lij * L[tri(i, j)]);
         }
     }
-    return result;
+    return (poison != poison) ? -1 : (negative ? 1 : 0);
 }
 
 // ------------------------------------------------------------------

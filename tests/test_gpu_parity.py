@@ -308,3 +308,42 @@ def test_batch_mpc_follows_reference_closed_loops(torch_gpu):
         assert rel_traj(xs[:steps, b], ref).max() < 1e-5, b
         st = q["stable"][b * steps:(b + 1) * steps] == 1
         assert np.array_equal(its[:, b][st], q["iters"][b * steps:(b + 1) * steps][st]), b
+
+
+def test_parts_on_internal_streams_do_not_change_results(torch_gpu, oracle):
+    """A batch large enough to be cut into concurrently running parts (odd size, stride > B, traces on) gives
+    bit-identical results to the same batch on the caller's stream alone, and leaves the padding untouched."""
+    import torch
+    from ilqr_amd import _lib
+    from ilqr_amd.batch import BatchSolver
+    rng = np.random.default_rng(11)
+    B, stride, N = 70001, 70080, 40
+    c = _cfg(oracle, "car")
+    x0, u0 = _car_box(rng, B), rng.standard_normal((B, N - 1, 2)) * 1e-4
+    res = []
+    for flags in (0, _lib.FLAG_SINGLE_STREAM):
+        s = BatchSolver(0, c["par"], N, 50, 20, 1e-3, trace_len=8, flags=flags)
+        x0s = torch.zeros((5, stride), dtype=torch.float64, device="cuda"); x0s[:, :B] = torch.as_tensor(x0).cuda().t()
+        us = torch.full((N - 1, 2, stride), 7.0, dtype=torch.float64, device="cuda")
+        us[:, :, :B] = torch.as_tensor(u0).cuda().permute(1, 2, 0)
+        xs = torch.full((N, 5, stride), -3.0, dtype=torch.float64, device="cuda")
+        out = s.alloc_outputs(stride)
+        for v in out.values():
+            v.fill_(0)
+        s.solve_soa(x0s, us, xs, out, B=B)
+        torch.cuda.synchronize()
+        assert (us[:, :, B:] == 7.0).all() and (xs[:, :, B:] == -3.0).all()
+        assert (out["iters"][B:] == 0).all() and (out["ls_evals"][:, B:] == 0).all()
+        res.append(dict(x=xs[:, :, :B].cpu().numpy(), u=us[:, :, :B].cpu().numpy(),
+                        **{k: v[..., :B].cpu().numpy() for k, v in out.items()}))
+    a, b = res
+    for k in a:
+        same = np.array_equal(a[k], b[k], equal_nan=True) if a[k].dtype.kind == "f" else np.array_equal(a[k], b[k])
+        assert same, k
+    assert a["iters"].min() >= 1 and set(np.unique(a["status"])) <= {0, 1, 2, 3}
+    # and the per-phase timing facility reports every phase of the solve
+    s = BatchSolver(0, c["par"], N, 50, 20, 1e-3, flags=_lib.FLAG_TIMING)
+    s.solve(x0[:4096], u0[:4096])
+    t = s.last_timing()
+    assert t["iterations"] >= 5 and t["backward"][1] == t["iterations"] and t["backward"][0] > 0
+    assert t["init"][1] == 1 and t["forward1"][1] >= 1
