@@ -296,7 +296,9 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
                 }
                 if (more) {
                     tm.begin(ILQR_PHASE_BACKTRACK);
-                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GB, true>), dim3(blocks_for(bound, 64 / GB)),
+                    // the list this stage works on is usually a fraction of `bound`: a capped grid strides over it
+                    const unsigned gb = blocks_for(bound, 64 / GB);
+                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GB, true>), dim3(gb < 4096u ? gb : 4096u),
                                        dim3(PIPE_WG), 0, st, a, lin, nin, (int32_t*)nullptr, (int32_t*)nullptr);
                     tm.end();
                     HIP_TRY(hipGetLastError());

@@ -306,46 +306,50 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_backtrack_group_kerne
     constexpr int PER_WAVE = 64 / GL;
     const int lane = threadIdx.x & 63;
     const int grp = lane / GL, g = lane % GL;
-    const int q = blockIdx.x * PER_WAVE + grp;
-    const bool live = q < *n_in;
-    int j = 0, s = 0, first_ls = 0;
-    double J = 0.0, deltaJ = 0.0;
-    if (live) {
-        j = list_in[q];
-        s = a.ls_slot[j];
-        first_ls = a.ls_from[j];
-        J = a.J[a.idA[s]];
-        deltaJ = a.dJ[s];
-    }
     const ParCache<M> par(a.par);
     const unsigned long long gmask = ((GL >= 64) ? ~0ull : ((1ull << GL) - 1ull)) << (grp * GL);
-    bool pending = live;
-    for (int base = first_ls; __ballot(pending) != 0ull; base += GL) {     // base differs between groups
-        const int ls = base + g;
-        bool stop = false, complete = false;
-        double Jn = 0.0;
-        if (pending && ls <= a.max_ls) {
-            double alpha = 1.0;
-            for (int i = 1; i < ls; ++i) alpha *= 0.5;                                 // :73
-            Jn = forward_cost<M>(par.get(), slot_T<M>(a.TA, a.cap, s), slot_G<M>(a, s), alpha, a.N - 1);
-            complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);          // :66
-            stop = complete || (Jn != Jn) || (ls >= a.max_ls);                         // :67
+    const int n = *n_in;
+    // grid-stride over the list: the host sizes the grid from an upper bound of the list's length
+    for (int q0 = blockIdx.x * PER_WAVE; q0 < n; q0 += gridDim.x * PER_WAVE) {
+        const int q = q0 + grp;
+        const bool live = q < n;
+        int j = 0, s = 0, first_ls = 0;
+        double J = 0.0, deltaJ = 0.0;
+        if (live) {
+            j = list_in[q];
+            s = a.ls_slot[j];
+            first_ls = a.ls_from[j];
+            J = a.J[a.idA[s]];
+            deltaJ = a.dJ[s];
         }
-        const unsigned long long stops = __ballot(stop) & gmask;
-        if (pending && stops) {
-            if (lane == __ffsll((long long)stops) - 1) {
-                a.win_ls[j] = complete ? ls : -ls;
-                a.win_J[j] = Jn;
+        bool pending = live;
+        for (int base = first_ls; __ballot(pending) != 0ull; base += GL) {     // base differs between groups
+            const int ls = base + g;
+            bool stop = false, complete = false;
+            double Jn = 0.0;
+            if (pending && ls <= a.max_ls) {
+                double alpha = 1.0;
+                for (int i = 1; i < ls; ++i) alpha *= 0.5;                                 // :73
+                Jn = forward_cost<M>(par.get(), slot_T<M>(a.TA, a.cap, s), slot_G<M>(a, s), alpha, a.N - 1);
+                complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);          // :66
+                stop = complete || (Jn != Jn) || (ls >= a.max_ls);                         // :67
             }
-            pending = false;
+            const unsigned long long stops = __ballot(stop) & gmask;
+            if (pending && stops) {
+                if (lane == __ffsll((long long)stops) - 1) {
+                    a.win_ls[j] = complete ? ls : -ls;
+                    a.win_J[j] = Jn;
+                }
+                pending = false;
+            }
+            if (!REPEAT) break;
         }
-        if (!REPEAT) break;
-    }
-    if (!REPEAT) {
-        const int o = wave_append(pending && g == 0, n_out);
-        if (pending && g == 0) {
-            list_out[o] = j;
-            a.ls_from[j] = first_ls + GL;
+        if (!REPEAT) {
+            const int o = wave_append(pending && g == 0, n_out);
+            if (pending && g == 0) {
+                list_out[o] = j;
+                a.ls_from[j] = first_ls + GL;
+            }
         }
     }
 }
