@@ -19,7 +19,7 @@ FLAG_PARALLEL_LS = 1
 FLAG_LS_SEQUENTIAL = 2
 FLAG_TIMING = 4
 FLAG_SINGLE_STREAM = 8
-PHASES = ("init", "backward", "forward1", "backtrack", "commit")
+PHASES = ("init", "backward", "forward1", "backtrack", "commit", "export")
 
 EXPORTS = ("ilqr_model_info", "ilqr_workspace_bytes", "ilqr_solve_batch", "ilqr_rollout_cost",
            "ilqr_model_eval", "ilqr_mpc_advance", "ilqr_last_timing", "ilqr_last_error", "ilqr_version")
@@ -39,7 +39,7 @@ class Outputs(C.Structure):
 
 
 class Timing(C.Structure):
-    _fields_ = [("ms", C.c_double * 5), ("launches", C.c_int32 * 5), ("iterations", C.c_int32), ("pad_", C.c_int32 * 2)]
+    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_int32 * 6), ("iterations", C.c_int32), ("pad_", C.c_int32)]
 
 
 class LibraryMissing(RuntimeError):

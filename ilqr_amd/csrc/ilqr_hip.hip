@@ -147,7 +147,7 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
 }
 
 struct WsLayout {
-    size_t TA, TB, G, Gscratch, dJ, J0, J, dmax, maxq, iters, status, regu_rounds, regu_stages, ls_total, idA, idB,
+    size_t TA, TB, TOUT, G, Gscratch, dJ, J0, J, dmax, maxq, iters, status, regu_rounds, regu_stages, ls_total, idA, idB,
         ls_slot, ls_dest, bt, bt2, ls_from, pred, win_ls, win_J, cnt, total;
 };
 WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
@@ -157,7 +157,7 @@ WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     WsLayout w;
-    w.TA = take(N * RT * cap * 8); w.TB = take(N * RT * cap * 8);
+    w.TA = take(N * RT * cap * 8); w.TB = take(N * RT * cap * 8); w.TOUT = take(N * RT * cap * 8);
     w.G = take(S * RG * cap * 8);
     w.Gscratch = take(S * RG * 8);
     w.dJ = take(cap * 8);
@@ -234,6 +234,10 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
     if (!(INFINITY > a.d_tol) || !(0 < a.max_iter)) {
         const int status = !(INFINITY > a.d_tol) ? ILQR_EXIT_DTOL : ILQR_EXIT_MAXITER;
         hipLaunchKernelGGL(pipe_finish_all_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a, status);
+        HIP_TRY(hipGetLastError());
+        tm.begin(ILQR_PHASE_EXPORT);
+        hipLaunchKernelGGL(pipe_export_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+        tm.end();
         HIP_TRY(hipGetLastError());
         return tm.finish(0, tout);
     }
@@ -315,6 +319,10 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
         int32_t* ti = a.idA; a.idA = a.idB; a.idB = ti;
         count = next;
     }
+    tm.begin(ILQR_PHASE_EXPORT);
+    hipLaunchKernelGGL(pipe_export_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+    tm.end();
+    HIP_TRY(hipGetLastError());
     return tm.finish(iters_run, tout);
 }
 
@@ -330,7 +338,7 @@ Pipe part_of(Pipe a, long lo, long n, int part)
     if (a.tr_acc) a.tr_acc += lo;
     if (a.tr_J) a.tr_J += lo;
     if (a.tr_dJ) a.tr_dJ += lo;
-    a.TA += lo * Rec<M>::RT; a.TB += lo * Rec<M>::RT; a.G += lo * Rec<M>::RG; a.dJ += lo;
+    a.TA += lo * Rec<M>::RT; a.TB += lo * Rec<M>::RT; a.TOUT += lo * Rec<M>::RT; a.G += lo * Rec<M>::RG; a.dJ += lo;
     a.idA += lo; a.idB += lo; a.ls_slot += lo; a.ls_dest += lo; a.bt += lo; a.bt2 += lo;
     a.ls_from += lo; a.pred += lo; a.win_ls += lo; a.win_J += lo;
     a.cnt += 64 * part;
@@ -378,7 +386,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     a.regu_stages = o.regu_stages ? o.regu_stages : (int32_t*)(ws + w.regu_stages);
     a.ls_total = o.ls_total ? o.ls_total : (int32_t*)(ws + w.ls_total);
     a.tr_ls = o.ls_evals; a.tr_acc = o.accepted; a.tr_J = o.J_trace; a.tr_dJ = o.deltaJ_trace;
-    a.TA = (double*)(ws + w.TA); a.TB = (double*)(ws + w.TB); a.G = (double*)(ws + w.G); a.Gscratch = (double*)(ws + w.Gscratch); a.dJ = (double*)(ws + w.dJ);
+    a.TA = (double*)(ws + w.TA); a.TB = (double*)(ws + w.TB); a.TOUT = (double*)(ws + w.TOUT); a.G = (double*)(ws + w.G); a.Gscratch = (double*)(ws + w.Gscratch); a.dJ = (double*)(ws + w.dJ);
     a.idA = (int32_t*)(ws + w.idA); a.idB = (int32_t*)(ws + w.idB);
     a.ls_slot = (int32_t*)(ws + w.ls_slot); a.ls_dest = (int32_t*)(ws + w.ls_dest);
     a.bt = (int32_t*)(ws + w.bt); a.bt2 = (int32_t*)(ws + w.bt2);

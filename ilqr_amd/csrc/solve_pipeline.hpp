@@ -14,6 +14,7 @@
 //   group<4>  candidates 2..5 of the rejected ones side by side, cost only
 //   group<16> candidates 6.. of those still searching, 16 at a time, cost only
 //   commit    the candidate each backtracking search stopped at is written (:66-72)
+//   export    finished trajectories, record layout -> the caller's strided arrays (:84)
 //
 // State of a running trajectory (x, u) lives in one of two slot-indexed record
 // buffers (solver_device.hpp, Rec); the forward pass, which has to write the
@@ -21,7 +22,8 @@
 // the next iteration (slots are handed out densely with one wave-aggregated
 // atomic per wavefront), so the big kernels read and write contiguous spans
 // although the set of running trajectories keeps shrinking.  A trajectory
-// that finishes writes its result to the caller's arrays at its own index.
+// that finishes writes its result, still as records, to an export buffer at
+// its own index, and one last coalesced pass fills the caller's arrays.
 // Results per trajectory do not depend on the slot order.
 //
 // Line search.  The reference tries alpha = 1, 1/2, 1/4, ... one after the
@@ -66,6 +68,7 @@ struct Pipe {
     double *tr_J, *tr_dJ;
     // slot-indexed buffers
     double *TA, *TB, *G, *dJ;  // T records now / next iteration, G records, expected reduction
+    double* TOUT;              // T records of finished trajectories, indexed by trajectory (export buffer)
     double* Gscratch;          // G records of one trajectory that lanes without a trajectory may write to
     int32_t *idA, *idB, *ls_slot, *ls_dest, *bt, *bt2;
     int32_t* ls_from;          // per line-search entry: number of the first evaluation still to be made
@@ -106,19 +109,20 @@ __device__ __forceinline__ RecIn slot_G(const Pipe& a, int s)
 {
     return RecIn{a.G + (long)s * Rec<M>::RG, a.cap * Rec<M>::RG};
 }
+// A finished trajectory goes to the export buffer, record layout, at its own index; one coalesced pass
+// at the end of the solve (pipe_export_kernel) turns that buffer into the caller's strided arrays.
+// (Writing the caller's arrays directly would scatter 8-byte stores over the batch.)
 template <class M>
-__device__ __forceinline__ Dest<M> caller_dest(const Pipe& a, int id)
+__device__ __forceinline__ Dest<M> final_dest(const Pipe& a, int id)
 {
-    return Dest<M>{nullptr, 0, a.x + id, a.u + id, a.cap};
+    return Dest<M>{a.TOUT + (long)id * Rec<M>::RT, a.cap * Rec<M>::RT};
 }
 // Where a line-search candidate is written: the trajectory's slot in the next
-// iteration's buffer, or straight into the caller's arrays when this was its
-// last iteration.
+// iteration's buffer, or the export buffer when this was its last iteration.
 template <class M>
 __device__ __forceinline__ Dest<M> make_dest(const Pipe& a, int dest, int id)
 {
-    return dest >= 0 ? Dest<M>{a.TB + (long)dest * Rec<M>::RT, a.cap * Rec<M>::RT, nullptr, nullptr, 0}
-                     : caller_dest<M>(a, id);
+    return dest >= 0 ? Dest<M>{a.TB + (long)dest * Rec<M>::RT, a.cap * Rec<M>::RT} : final_dest<M>(a, id);
 }
 
 // ---------------------------------------------------------------- init
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
     const int S = a.N - 1;
     double xs[nx];
     for (int i = 0; i < nx; ++i) xs[i] = a.x0[(long)i * a.cap + b];
-    const Dest<M> out{a.TA + b * Rec<M>::RT, a.cap * Rec<M>::RT, nullptr, nullptr, 0};
+    const Dest<M> out{a.TA + b * Rec<M>::RT, a.cap * Rec<M>::RT};
     const double J = rollout_cost_rec<M>(ParCache<M>(a.par).get(), xs, CLane{a.u + b, a.cap}, out, S);     // iLQRController.py:27-34
     a.idA[b] = (int)b;
     a.J0[b] = J;
@@ -147,14 +151,38 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
 }
 
 // The loop test of :43 failed before the first iteration (d_tol is +inf/NaN or
-// max_iter == 0): the initial rollout is the result (u is left as it came).
+// max_iter == 0): the initial rollout is the result.
 template <class M>
 __global__ __launch_bounds__(PIPE_WG) void pipe_finish_all_kernel(Pipe a, int status)
 {
     const long b = (long)blockIdx.x * PIPE_WG + threadIdx.x;
     if (b >= a.B) return;
-    copy_traj<M>(slot_T<M>(a.TA, a.cap, (int)b), caller_dest<M>(a, (int)b), a.N - 1);
+    copy_traj<M>(slot_T<M>(a.TA, a.cap, (int)b), final_dest<M>(a, (int)b), a.N - 1);
     a.status[b] = status;
+}
+
+// ---------------------------------------------------------------- export
+// Record layout -> the caller's strided arrays x [N][nx][cap], u [N-1][nu][cap]; reads and writes of
+// consecutive lanes are contiguous.
+template <class M>
+__global__ __launch_bounds__(PIPE_WG) void pipe_export_kernel(Pipe a)
+{
+    constexpr int nx = M::NX, m = M::NU;
+    const long b = (long)blockIdx.x * PIPE_WG + threadIdx.x;
+    if (b >= a.B) return;
+    const int S = a.N - 1;
+    const RecIn T = slot_T<M>(a.TOUT, a.cap, (int)b);
+    double xu[nx + m];
+    for (int k = 0; k < S; ++k) {
+        load_rec<nx + m>(T.p + (long)k * T.ss, xu);
+#pragma unroll
+        for (int i = 0; i < nx; ++i) a.x[(long)(k * nx + i) * a.cap + b] = xu[i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) a.u[(long)(k * m + i) * a.cap + b] = xu[nx + i];
+    }
+    load_rec<nx>(T.p + (long)S * T.ss, xu);
+#pragma unroll
+    for (int i = 0; i < nx; ++i) a.x[(long)(S * nx + i) * a.cap + b] = xu[i];
 }
 
 // ---------------------------------------------------------------- backward
@@ -196,7 +224,7 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
             if (!cont) a.status[id] = (dmax > a.d_tol) ? ILQR_EXIT_MAXITER : ILQR_EXIT_DTOL;
         }
         if (!need_ls)   // finished with the trajectory it came in with (:84)
-            copy_traj<M>(T, caller_dest<M>(a, id), S);
+            copy_traj<M>(T, final_dest<M>(a, id), S);
     }
     const int j = wave_append(need_ls, a.cnt + 1);
     const int ns = wave_append(cont, a.cnt + 0);

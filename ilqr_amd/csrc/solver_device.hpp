@@ -702,41 +702,23 @@ struct ParCache<M, false> {
     __device__ __forceinline__ const double* get() const { return p; }
 };
 
-// Where a new trajectory goes: a slot of a record buffer, or the caller's
-// strided arrays x [N][nx][cs], u [S][nu][cs] at the trajectory's own index.
+// Where a new trajectory goes: the T records of a slot (of the next iteration's buffer, or of the
+// trajectory's own place in the export buffer when the solve ends with it).
 template <class M>
 struct Dest {
     static constexpr int nx = M::NX, m = M::NU;
-    double* t;
-    long ts;
-    double* x;
-    double* u;
-    long cs;
+    double* t;      // record of stage 0
+    long ts;        // doubles between consecutive stages
     __device__ __forceinline__ void stage(int k, const double* xv, const double* uv) const
     {
-        if (t) {
-            double r[nx + m];
+        double r[nx + m];
 #pragma unroll
-            for (int i = 0; i < nx; ++i) r[i] = xv[i];
+        for (int i = 0; i < nx; ++i) r[i] = xv[i];
 #pragma unroll
-            for (int i = 0; i < m; ++i) r[nx + i] = uv[i];
-            store_rec<nx + m>(t + (long)k * ts, r);
-        } else {
-#pragma unroll
-            for (int i = 0; i < nx; ++i) x[(long)(k * nx + i) * cs] = xv[i];
-#pragma unroll
-            for (int i = 0; i < m; ++i) u[(long)(k * m + i) * cs] = uv[i];
-        }
+        for (int i = 0; i < m; ++i) r[nx + i] = uv[i];
+        store_rec<nx + m>(t + (long)k * ts, r);
     }
-    __device__ __forceinline__ void last(int k, const double* xv) const
-    {
-        if (t) {
-            store_rec<nx>(t + (long)k * ts, xv);
-        } else {
-#pragma unroll
-            for (int i = 0; i < nx; ++i) x[(long)(k * nx + i) * cs] = xv[i];
-        }
-    }
+    __device__ __forceinline__ void last(int k, const double* xv) const { store_rec<nx>(t + (long)k * ts, xv); }
 };
 
 // ------------------------------------------------------------------
@@ -877,7 +859,7 @@ __device__ inline double forward_pass(const double* par, const RecIn& T, const R
 template <class M>
 __device__ inline double forward_cost(const double* par, const RecIn& T, const RecIn& G, double alpha, int S)
 {
-    return forward_pass<M, false>(par, T, G, alpha, Dest<M>{nullptr, 0, nullptr, nullptr, 0}, S);
+    return forward_pass<M, false>(par, T, G, alpha, Dest<M>{nullptr, 0}, S);
 }
 
 // Copy of a trajectory (all T records) to `out`.

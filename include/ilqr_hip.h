@@ -78,7 +78,8 @@ enum {
     ILQR_PHASE_FORWARD1 = 2,  /* first line-search candidate, alpha = 1   (:60-68, :87-96) */
     ILQR_PHASE_BACKTRACK = 3, /* later candidates (cost only or one launch per candidate) */
     ILQR_PHASE_COMMIT = 4,    /* writing the trajectory a backtracking search ended with */
-    ILQR_PHASE_COUNT = 5
+    ILQR_PHASE_EXPORT = 5,    /* finished trajectories -> the caller's x and u arrays  (:84) */
+    ILQR_PHASE_COUNT = 6
 };
 
 /* host struct: device time and launch count per phase of the last ilqr_solve_batch call that the calling
@@ -87,7 +88,7 @@ typedef struct {
     double ms[ILQR_PHASE_COUNT];
     int32_t launches[ILQR_PHASE_COUNT];
     int32_t iterations;   /* solver iterations the batch ran (the longest trajectory's) */
-    int32_t pad_[2];
+    int32_t pad_;
 } ilqr_timing;
 
 /* per-trajectory results; any pointer may be NULL.  Arrays are [B] (index b),

@@ -49,7 +49,7 @@ def test_struct_layout_matches_header():
     from ilqr_amd import _lib
     assert C.sizeof(_lib.Problem) == 56     # 4 int32, double, 2 int64, pointer, 2 int32
     assert C.sizeof(_lib.Outputs) == 13 * 8
-    assert C.sizeof(_lib.Timing) == 5 * 8 + 5 * 4 + 3 * 4
+    assert C.sizeof(_lib.Timing) == 6 * 8 + 6 * 4 + 2 * 4
 
 
 def test_argument_validation_and_workspace(L):
