@@ -18,8 +18,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 flops of the backward passes actually run (dense formulas, the batch's own
                 iteration / regularisation counts) / that kernel's summed device time in one
                 solve, timed with HIP events around each of its launches on the solve's stream
-                (ILQR_FLAG_TIMING, one extra solve after the timed region), against the fp64
-                peak.  `line_search` gives the same for the memory-bound forward-pass kernels
+                (ILQR_FLAG_TIMING | ILQR_FLAG_SINGLE_STREAM, one extra solve after the timed
+                region, kernels back to back), against the fp64 peak.  `line_search` gives the same for the memory-bound forward-pass kernels
                 against the HBM peak, `solve` for all kernels of a solve together;
   cpu_baseline: the CPU checker (oracle/, a C restatement of the reference solver) on a
                 bounded sample of the same batch, one OpenMP thread per host core.
@@ -148,13 +148,15 @@ def main():
         elapsed = float(t.item())
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
 
-    # one more solve with an event pair around every kernel launch (outside the timed region)
+    # one more solve with an event pair around every kernel launch (outside the timed region).  It runs the
+    # whole batch on one stream, so that a kernel's duration is its own: in the timed region the batch is cut
+    # into parts whose kernels overlap on the GPU and stretch each other.
     from ilqr_amd import _lib
-    solver.flags |= _lib.FLAG_TIMING
+    solver.flags |= _lib.FLAG_TIMING | _lib.FLAG_SINGLE_STREAM
     step()
     sync()
     phases = solver.last_timing()
-    solver.flags &= ~_lib.FLAG_TIMING
+    solver.flags &= ~(_lib.FLAG_TIMING | _lib.FLAG_SINGLE_STREAM)
 
     # counts of the work actually done (rank 0's shard; every shard is statistically alike)
     iters = int(out["iters"].sum().item())
@@ -201,6 +203,8 @@ def main():
                          "achieved": bw_tfl, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": bw_tfl / FP64_PEAK_TFLOPS,
                          "traffic": (traffic or {}).get("backward_hbm_bytes_per_solve"),
+                         "timing": "HIP events around each launch, one extra solve of the same batch on a single stream "
+                                   "(ILQR_FLAG_TIMING | ILQR_FLAG_SINGLE_STREAM); the timed region overlaps 3 parts",
                          "launches_per_solve": bw_launches, "kernel_ms_per_solve": bw_ms,
                          "avg_launch_ms": bw_ms / max(bw_launches, 1), "algorithmic_flops_per_solve": f_bwd,
                          "line_search": {"kernels": "pipe_forward1 / pipe_backtrack_group / pipe_commit", "bound": "hbm",

@@ -3,12 +3,12 @@
 WRITE_SIZE, --output-format csv) into profiles/traffic_latest.json, which bench.py reports as
 roofline.traffic.
 
-    python tools/collect_traffic.py <fetch_dir> <write_dir> <out.json>
+    python tools/collect_traffic.py <fetch_dir> <write_dir> <out.json> [solves]
 
 Bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and on gfx950 FETCH_SIZE counts
 half the bytes of 16-byte-per-lane streaming reads, which is how every solver kernel reads its records.
-The bench process runs two solves in this mode (the timed step and the per-phase timing step); per-solve
-figures are the totals divided by the number of init launches seen.
+The bench process runs `solves` whole-batch solves in this mode (default 2: the timed step and the per-phase
+timing step); per-solve figures are the totals divided by that number.
 """
 import collections
 import csv
@@ -36,7 +36,7 @@ def per_kernel(path, counter):
 def main():
     fetch, launches = per_kernel(sys.argv[1], "FETCH_SIZE")
     write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
-    solves = max(launches.get("init", 1), 1)
+    solves = int(sys.argv[4]) if len(sys.argv) > 4 else 2
     kib = {k: (2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) for k in set(fetch) | set(write)}
     b = {k: v * 1024.0 / solves for k, v in kib.items()}
     ls = sum(b.get(k, 0.0) for k in ("forward1", "backtrack_group", "forward_level", "commit"))
