@@ -15,6 +15,7 @@
 #include "../../include/ilqr_hip.h"
 #include "solver_device.hpp"
 #include "solve_pipeline.hpp"
+#include "team_backward.hpp"
 
 using namespace ilqr;
 
@@ -255,7 +256,15 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
         a.iter = iter;
         HIP_TRY(hipMemsetAsync(a.cnt, 0, 64 * sizeof(int32_t), st));
         tm.begin(ILQR_PHASE_BACKWARD);
-        hipLaunchKernelGGL(pipe_backward_kernel<M>, dim3(blocks_for(count, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+        if constexpr (M::TEAM_BACKWARD) {
+            if (a.flags & ILQR_FLAG_LANE_BACKWARD)
+                hipLaunchKernelGGL(pipe_backward_kernel<M>, dim3(blocks_for(count, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+            else
+                hipLaunchKernelGGL(pipe_backward_team_kernel<M>, dim3(blocks_for(count, PIPE_WG / TEAM_LANES)),
+                                   dim3(PIPE_WG), 0, st, a);
+        } else {
+            hipLaunchKernelGGL(pipe_backward_kernel<M>, dim3(blocks_for(count, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+        }
         tm.end();
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h, a.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));

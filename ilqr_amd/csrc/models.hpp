@@ -37,6 +37,7 @@ __device__ __forceinline__ void diff_sub(const double* s, const double* r, doubl
 struct CarModel {
     static constexpr int NX = 5, NU = 2, NDX = 5, NPAR = 2;
     static constexpr bool UNROLL = true;
+    static constexpr bool TEAM_BACKWARD = false;
     // waves per SIMD the backward kernel is built for: the stage's matrices need ~220 registers per lane, and
     // asking for 3 or 4 waves makes the compiler spill ~1 KB per lane (measured slower than 2 resident waves)
 #ifndef ILQR_CAR_BW
@@ -142,12 +143,44 @@ __device__ inline void rk4_jac(double dt, const double* x, const double* u, doub
     }
 }
 
+// Tangent of one RK4 step: d x_next along the direction (vx, vu), the same chain rule as rk4_jac applied
+// to one vector instead of the identity: d_i = A_i (vx + c_i d_(i-1)) + B_i vu.
+template <int NX, void (*XDOTJVP)(const double*, const double*, const double*, const double*, double*, double*)>
+__device__ inline void rk4_jvp(double dt, const double* x, const double* u, const double* vx, const double* vu,
+                               double* dxn)
+{
+    double f[NX], d[NX], acc[NX], xs[NX], vs[NX];
+    for (int i = 0; i < NX; ++i) { acc[i] = 0.0; f[i] = 0.0; d[i] = 0.0; }
+    // one copy of the (large) generated function: the four stages run through the same code
+#pragma unroll 1
+    for (int stage = 0; stage < 4; ++stage) {
+        const double c = (stage == 0) ? 0.0 : (stage == 3 ? 1.0 : 0.5);
+        const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
+        for (int i = 0; i < NX; ++i) {
+            xs[i] = (stage == 0) ? x[i] : x[i] + c * f[i] * dt;
+            vs[i] = (stage == 0) ? vx[i] : vx[i] + (c * dt) * d[i];
+        }
+        XDOTJVP(xs, u, vs, vu, f, d);
+        for (int i = 0; i < NX; ++i) acc[i] += wgt * d[i];
+    }
+    for (int i = 0; i < NX; ++i) dxn[i] = vx[i] + acc[i] * dt / 6.0;
+}
+
 // --------------------- quadratic-cost RK4 plants (acrobot.py, Quadrotor_EA.py)
 // parameter block: [dt, Q(nx*nx), Qf(nx*nx), R(nu*nu), xref(nx), uref(nu)]
 template <int NX_, int NU_, bool UNROLL_, void (*XDOT)(const double*, const double*, double*),
-          void (*XDOTJAC)(const double*, const double*, double*, double*, double*)>
+          void (*XDOTJAC)(const double*, const double*, double*, double*, double*),
+          void (*XDOTJVP)(const double*, const double*, const double*, const double*, double*, double*)>
 struct QuadraticRK4Model {
     static constexpr int NX = NX_, NU = NU_, NDX = NX_;
+    // 12 states + 4 controls: the backward pass runs with 16 lanes per trajectory (team_backward.hpp)
+    static constexpr bool TEAM_BACKWARD = (NX_ == 12 && NU_ == 4);
+    // one column (or any combination of columns) of [d x_next/dx, d x_next/du]
+    __device__ static void dynamics_jvp(const double* par, const double* x, const double* u, const double* vx,
+                                        const double* vu, double* dxn)
+    {
+        rk4_jvp<NX, XDOTJVP>(par[0], x, u, vx, vu, dxn);
+    }
     static constexpr int NPAR = 1 + 2 * NX * NX + NU * NU + NX + NU;
     static constexpr bool UNROLL = UNROLL_;
     static constexpr int BACKWARD_WAVES = 1;
@@ -223,14 +256,15 @@ struct QuadraticRK4Model {
     }
 };
 
-using AcrobotModel = QuadraticRK4Model<4, 1, true, acrobot_gen_xdot, acrobot_gen_xdot_jac>;
-using QuadEAModel = QuadraticRK4Model<12, 4, false, quad_ea_gen_xdot, quad_ea_gen_xdot_jac>;
+using AcrobotModel = QuadraticRK4Model<4, 1, true, acrobot_gen_xdot, acrobot_gen_xdot_jac, acrobot_gen_xdot_jvp>;
+using QuadEAModel = QuadraticRK4Model<12, 4, false, quad_ea_gen_xdot, quad_ea_gen_xdot_jac, quad_ea_gen_xdot_jvp>;
 
 // ------------------------------------ quaternion quadrotor (Quadrotor_Quat.py)
 // parameter block: [dt, qdiag(12), qfdiag(12), rdiag(4), xref(13), uref(4)]
 struct QuadQuatModel {
     static constexpr int NX = 13, NU = 4, NDX = 12, NPAR = 1 + 12 + 12 + 4 + 13 + 4;
     static constexpr bool UNROLL = false;
+    static constexpr bool TEAM_BACKWARD = true;      // 16 lanes per trajectory (team_backward.hpp)
     static constexpr int BACKWARD_WAVES = 1;
     __device__ static const double* qd(const double* p) { return p + 1; }
     __device__ static const double* qfd(const double* p) { return p + 13; }

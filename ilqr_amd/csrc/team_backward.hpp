@@ -1,0 +1,522 @@
+// Backward pass of the 12-state / 4-control plants with SIXTEEN LANES PER TRAJECTORY.
+//
+// One lane per trajectory does not work for these plants: a stage needs f_x (12x12), f_u,
+// V_xx, the 16x16 Q-function Hessian and its factorisation, about 1000 doubles per lane that
+// end up in scratch memory, and the kernel crawls on scratch latency.  Here a wavefront holds
+// four trajectories; lane j of a team of 16 owns column j of [f_x f_u] and row j of Q, V_xx
+// and P, everything shared sits in LDS (4 KB per team), and nothing spills.
+//
+//   column j of [f_x f_u]   one forward-mode derivative through the RK4 step along unit
+//                           vector j (12 + 4 = 16 directions = 16 lanes), Model.stage
+//   row j of Q, P           Q = l_zz + F'(V F) in the reference's order ((F'V) F), model.py:45-53;
+//                           P = (0.1 F)'F, iLQRController.py:111-113
+//   PSD test                the same unpivoted LDL' with the same tolerance rule as the
+//                           one-lane version, rows distributed over lanes, pivot column
+//                           exchanged through LDS (iLQRController.py:110)
+//   regularisation          team by team: Q + (2^r - 1) P for r = 1, 2, ... (:106-115)
+//   gains, V, reduction     :125-137; V_xx is kept as full rows, as in the reference
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "solve_pipeline.hpp"
+
+namespace ilqr {
+
+constexpr int TEAM_LANES = 16;
+constexpr int TEAM_LDS = 512;       // doubles of LDS per team
+constexpr int TEAM_REGU_LINEAR = 16; // regularisation rounds tried one by one
+constexpr int TEAM_REGU_MAX = 1300;  // 0.1 * 2^r is infinite long before
+
+// Offsets (doubles) inside a team's LDS region
+namespace tl {
+constexpr int F = 0;        // [12][16]  column c of [f_x f_u] in F[r * 16 + c]
+constexpr int V = 192;      // [12][12]  V_xx rows
+constexpr int VX = 336;     // [12]
+constexpr int QR = 348;     // [4][16]   rows 12..15 of Q: [Q_ux Q_uu]
+constexpr int QZ = 412;     // [16]      [Q_x Q_u]
+constexpr int GB = 428;     // [4 + 48]  the stage's G record: d, then K row-major
+constexpr int COL = 480;    // [16 + 1]  pivot column exchange, then the pivot's tolerance
+}  // namespace tl
+
+// `np.any(np.linalg.eigvals(Q) < 0)` for the 16x16 matrix whose row i (entries 0..i-1 in Lr, diagonal in
+// diag) is held by lane i of the team.  Same rule as has_negative_eig_packed.  Lr and diag are destroyed.
+// Returns 1 / 0 / -1, the same value in all lanes of a team.  All 64 lanes must call it together.
+__device__ inline int team_has_negative_eig(double* Lr, double diag, int i, unsigned long long tmask, double* col,
+                                            double& maxq)
+{
+    double mq = fmax(maxq, fabs(diag));
+    double poison = __builtin_fma(0.0, diag, 0.0);
+#pragma unroll
+    for (int c = 0; c < TEAM_LANES - 1; ++c) {
+        const double v = (c < i) ? Lr[c] : 0.0;
+        mq = fmax(mq, fabs(v));
+        poison = __builtin_fma(0.0, v, poison);
+    }
+    maxq = mq;
+    const bool bad = (__ballot(poison != poison) & tmask) != 0ull;
+    double acc = fabs(diag);
+    bool negative = false;
+#pragma unroll
+    for (int p = 0; p < TEAM_LANES; ++p) {
+        const double c = (p < TEAM_LANES - 1) ? Lr[p < TEAM_LANES - 1 ? p : 0] : 0.0;     // L[i][p], meaningful for i > p
+        wave_sync();
+        col[i] = (i == p) ? diag : c;
+        if (i == p) col[TEAM_LANES] = PIVOT_TOL * acc;
+        wave_sync();
+        const double d = col[p], thr = col[TEAM_LANES];
+        const bool neg = d < -thr;
+        const bool zero = !neg && (d <= thr);
+        const bool nz = (i > p) && (c * c > 4.0 * thr * fabs(diag));
+        const bool any_nz = (__ballot(nz) & tmask) != 0ull;
+        negative = negative || neg || (zero && any_nz);
+        double pinv = __builtin_amdgcn_rcp(d);
+        pinv = __builtin_fma(__builtin_fma(-d, pinv, 1.0), pinv, pinv);
+        pinv = __builtin_fma(__builtin_fma(-d, pinv, 1.0), pinv, pinv);
+        pinv = (zero || negative) ? 0.0 : pinv;
+        if (i > p) {
+            const double lij = c * pinv;
+#pragma unroll
+            for (int k = p + 1; k < TEAM_LANES - 1; ++k)
+                if (k < i) Lr[k] -= lij * col[k];
+            diag -= lij * c;
+            acc += fabs(lij * c);
+        }
+    }
+    return bad ? -1 : (negative ? 1 : 0);
+}
+
+// ------------------------------------------------------------------
+// What the team kernel asks of a plant (lane j of a team, all 16 lanes call together):
+//   SHARED            doubles of LDS per workgroup for data common to all teams (filled by setup)
+//   EXTRA             doubles of LDS per team for the plant's own scratch
+//   setup             once per kernel
+//   column            column j of [f_x f_u] at (x, u)                         -> col[12]
+//   cost_row          l_z[j] and row j of l_zz = [[l_xx, l_ux'], [l_ux, l_uu]] -> lz, lzz[16]
+//   final_row         V_x[j] and row j of V_xx at the last knot point (j < 12)  -> vx, vrow[12]
+// ------------------------------------------------------------------
+template <class M>
+struct TeamOps;
+
+// quadratic cost, state = error state (acrobot.py:152-166 / Quadrotor_EA.py:210-224)
+template <bool U, void (*XD)(const double*, const double*, double*),
+          void (*XJ)(const double*, const double*, double*, double*, double*),
+          void (*XV)(const double*, const double*, const double*, const double*, double*, double*)>
+struct TeamOps<QuadraticRK4Model<12, 4, U, XD, XJ, XV>> {
+    using M = QuadraticRK4Model<12, 4, U, XD, XJ, XV>;
+    static constexpr int n = 12, m = 4, w = 16;
+    static constexpr int SHARED = w * w, EXTRA = 0;
+    __device__ static void setup(const double* par, int lane, double* shared)
+    {
+        for (int e = lane; e < w * w; e += PIPE_WG) {       // l_zz = blkdiag(Q, R)
+            const int rj = e / w, c = e % w;
+            double v = 0.0;
+            if (rj < n && c < n) v = M::Qm(par)[rj * n + c];
+            if (rj >= n && c >= n) v = M::Rm(par)[(rj - n) * m + (c - n)];
+            shared[e] = v;
+        }
+    }
+    __device__ static void column(const double* par, const double* xu, int j, double*, double* col)
+    {
+        double vx[n], vu[m];
+#pragma unroll
+        for (int c = 0; c < n; ++c) vx[c] = (c == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int c = 0; c < m; ++c) vu[c] = (c + n == j) ? 1.0 : 0.0;
+        M::dynamics_jvp(par, xu, xu + n, vx, vu, col);
+    }
+    __device__ static void cost_row(const double* par, const double* xu, int j, const double* shared, double*,
+                                    double& lz, double* lzz)
+    {
+        const double* const row = shared + j * w;
+        double sx = 0.0, su = 0.0;
+#pragma unroll
+        for (int c = 0; c < w; ++c) lzz[c] = row[c];
+#pragma unroll
+        for (int c = 0; c < n; ++c) sx += lzz[c] * (xu[c] - M::xref(par)[c]);
+#pragma unroll
+        for (int c = 0; c < m; ++c) su += lzz[n + c] * (xu[n + c] - M::uref(par)[c]);
+        lz = (j < n) ? sx : su;
+    }
+    __device__ static void final_row(const double* par, const double* x, int j, double*, double& vx, double* vrow)
+    {
+        double sx = 0.0;
+        const int jj = (j < n) ? j : 0;
+#pragma unroll
+        for (int c = 0; c < n; ++c) {
+            const double q = M::Qf(par)[jj * n + c];
+            vrow[c] = q;
+            sx += q * (x[c] - M::xref(par)[c]);
+        }
+        vx = sx;
+    }
+};
+
+// quaternion quadrotor: 13 states, 12-dim error state through Gx = blkdiag(G(q), I9)
+// (Quadrotor_Quat.py:142-175, :231-238, :259-275)
+template <>
+struct TeamOps<QuadQuatModel> {
+    using M = QuadQuatModel;
+    static constexpr int n = 12, m = 4, w = 16;
+    static constexpr int SHARED = 0, EXTRA = 13 + 4 + 169;
+    __device__ static void setup(const double*, int, double*) {}
+    // entry (t, c) of Gx [13 x 12]
+    __device__ static double gx(const double* G, int t, int c)
+    {
+        if (t < 4) return (c < 3) ? G[t * 3 + c] : 0.0;
+        return (t - 1 == c) ? 1.0 : 0.0;
+    }
+    // out[c] = sum_t v[t] Gx[t][c]  (a 13-vector times Gx), entry c
+    __device__ static double times_gx(const double* G, const double* v, int c)
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s += v[t] * G[t * 3 + (c < 3 ? c : 0)];
+        double pick = 0.0;
+#pragma unroll
+        for (int t = 4; t < 13; ++t) pick = (t - 1 == c) ? v[t] : pick;
+        return (c < 3) ? s : pick;
+    }
+    __device__ static void column(const double* par, const double* xu, int j, double*, double* col)
+    {
+        double G[12], vx[13], vu[m], dxn[13];
+        quad_quat_gen_G(xu, G);
+#pragma unroll
+        for (int t = 0; t < 13; ++t) vx[t] = (j < n) ? gx(G, t, j) : 0.0;
+#pragma unroll
+        for (int c = 0; c < m; ++c) vu[c] = (c + n == j) ? 1.0 : 0.0;
+        rk4_jvp<13, quad_quat_gen_xdot_jvp>(par[0], xu, xu + 13, vx, vu, dxn);
+        // Gx' (A v): rows 0..2 through G, the rest shifted by one
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            if (i < 3) {
+                double s = 0.0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) s += G[t * 3 + i] * dxn[t];
+                col[i] = s;
+            } else {
+                col[i] = dxn[i + 1];
+            }
+        }
+    }
+    // row j (j < 12) of Gx' H Gx and entry j of g Gx for the 13-dim gradient g and Hessian H held in `ex`
+    __device__ static void project_row(const double* G, const double* ex, int j, double& gj, double* row)
+    {
+        const double* const g13 = ex;
+        const double* const H = ex + 17;
+        gj = times_gx(G, g13, j);
+        double T1[13];      // row j of Gx' H
+#pragma unroll
+        for (int c = 0; c < 13; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s += G[t * 3 + (j < 3 ? j : 0)] * H[t * 13 + c];
+            const double pick = H[((j < 3 ? 3 : j) + 1) * 13 + c];
+            T1[c] = (j < 3) ? s : pick;
+        }
+#pragma unroll
+        for (int c = 0; c < n; ++c) row[c] = times_gx(G, T1, c);
+    }
+    __device__ static void cost_row(const double* par, const double* xu, int j, const double*, double* ex,
+                                    double& lz, double* lzz)
+    {
+        double wgt[33], G[12];
+        M::weights(par, false, wgt);
+        quad_quat_gen_G(xu, G);
+        // every lane of the team writes the same values: l_x (13), l_u (4), l_xx (13 x 13)
+        quad_quat_gen_cost_derivs(wgt, xu, xu + 13, ex, ex + 13, ex + 17);
+        wave_sync();
+        double gj, row[n];
+        project_row(G, ex, (j < n) ? j : 0, gj, row);
+#pragma unroll
+        for (int c = 0; c < n; ++c) lzz[c] = (j < n) ? row[c] : 0.0;                      // l_ux = 0
+#pragma unroll
+        for (int c = 0; c < m; ++c) lzz[n + c] = (j >= n && c == j - n) ? M::rd(par)[c] : 0.0;   // l_uu = diag(rd)
+        lz = (j < n) ? gj : ex[13 + (j - n)];
+    }
+    __device__ static void final_row(const double* par, const double* x, int j, double* ex, double& vx, double* vrow)
+    {
+        double wgt[33], G[12];
+        M::weights(par, true, wgt);
+        quad_quat_gen_G(x, G);
+        quad_quat_gen_cost_derivs(wgt, x, M::uref(par), ex, ex + 13, ex + 17);
+        wave_sync();
+        project_row(G, ex, (j < n) ? j : 0, vx, vrow);
+    }
+};
+
+template <class M>
+__global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
+{
+    using OPS = TeamOps<M>;
+    constexpr int n = 12, m = 4, w = 16, nx = M::NX;
+    static_assert(M::NDX == n && M::NU == m, "team backward pass is written for a 12-dim error state and 4 controls");
+    static_assert(Rec<M>::RG == 52, "record sizes");
+    constexpr int TEAM_ALL = TEAM_LDS + OPS::EXTRA;
+    __shared__ double lds_all[(PIPE_WG / TEAM_LANES) * TEAM_ALL];
+    __shared__ double shared_all[OPS::SHARED > 0 ? OPS::SHARED : 1];
+    const int lane = threadIdx.x & 63, team = lane / TEAM_LANES, j = lane % TEAM_LANES;
+    const unsigned long long tmask = 0xFFFFull << (team * TEAM_LANES);
+    double* const L = lds_all + team * TEAM_ALL;
+    double* const EX = L + TEAM_LDS;          // the plant's own per-team scratch
+    const int s0 = blockIdx.x * (PIPE_WG / TEAM_LANES) + team;
+    const bool live = s0 < a.count;
+    const int s = live ? s0 : a.count - 1;      // a team without a trajectory shadows the last one
+    const int S = a.N - 1;
+    const int id = a.idA[s];
+    const double* const par = a.par;
+    const RecIn T = slot_T<M>(a.TA, a.cap, s);
+    double* const Gp = live ? a.G + (long)s * Rec<M>::RG : a.Gscratch;
+    const long Gss = live ? a.cap * Rec<M>::RG : Rec<M>::RG;
+    const int it = a.iters[id] + 1;                                                  // iLQRController.py:46
+
+    OPS::setup(par, lane, shared_all);
+    wave_sync();
+
+    // terminal condition (final(): V_x, V_xx at the last knot point)
+    double xu[nx + m];
+    load_rec<nx>(T.p + (long)S * T.ss, xu);
+    {
+        double vxj, vrow[n];
+        OPS::final_row(par, xu, j, EX, vxj, vrow);
+        if (j < n) {
+#pragma unroll
+            for (int c = 0; c < n; ++c) L[tl::V + j * n + c] = vrow[c];
+            L[tl::VX + j] = vxj;
+        }
+    }
+    double redu = 0.0, best = -INFINITY, maxq = a.maxq[id];
+    bool anynan = false, ok = true;
+    int rr = 0, rs = 0;
+
+    for (int k = S - 1; k >= 0; --k) {
+        load_rec<nx + m>(T.p + (long)k * T.ss, xu);
+        const bool alive = live && ok;
+        // ---- column j of F = [f_x f_u]: derivative of the RK4 step along unit vector j
+        double col[n];
+        OPS::column(par, xu, j, EX, col);
+        wave_sync();        // everybody is done with the previous stage's LDS data
+#pragma unroll
+        for (int r = 0; r < n; ++r) L[tl::F + r * w + j] = col[r];
+        // ---- l_z[j] and row j of l_zz
+        double lz, lzz[w];
+        OPS::cost_row(par, xu, j, shared_all, EX, lz, lzz);
+        // ---- Q_z[j] = l_z[j] + F[:,j] . V_x ;  srow = F[:,j]' V_xx
+        double qz, srow[n];
+        {
+            double sv = 0.0;
+#pragma unroll
+            for (int r = 0; r < n; ++r) sv += col[r] * L[tl::VX + r];
+            qz = lz + sv;
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int r = 0; r < n; ++r) sacc += col[r] * L[tl::V + r * n + c];
+                srow[c] = sacc;
+            }
+        }
+        wave_sync();        // F complete
+        // ---- row j of Q = l_zz + (F'V) F and of P = (0.1 F)'F
+        double Qrow[w], Prow[w];
+#pragma unroll
+        for (int c = 0; c < w; ++c) {
+            double sq = 0.0, sp = 0.0;
+#pragma unroll
+            for (int r = 0; r < n; ++r) {
+                const double f = L[tl::F + r * w + c];
+                sq += srow[r] * f;
+                sp += (0.1 * col[r]) * f;
+            }
+            Qrow[c] = lzz[c] + sq;
+            Prow[c] = sp;
+        }
+        L[tl::QZ + j] = qz;
+        double qdiag = 0.0, pdiag = 0.0;        // own diagonal entries (lane-dependent position)
+#pragma unroll
+        for (int c = 0; c < w; ++c) {
+            qdiag = (c == j) ? Qrow[c] : qdiag;
+            pdiag = (c == j) ? Prow[c] : pdiag;
+        }
+
+        // ---- regularisation loop (:106-115): first r = 0, 1, 2, ... whose Q + (2^r - 1) P has no negative
+        // eigenvalue.  One loop for all four teams; a team that has its answer idles through the others' tests.
+        // Rounds up to TEAM_REGU_LINEAR are tried one after the other like the reference does.  A trajectory that
+        // needs more (entries of Q around 1e200 can take a thousand doublings) is searched by doubling r until
+        // the test stops failing and bisecting back to the first such r: the same answer as the one-by-one
+        // scan whenever "has a negative eigenvalue" does not switch back on as r grows, in ~20 tests.
+        int r_lo = -1, r_hi = -1, neg_hi = 0;          // last failing round, first known stopping round
+        bool testing = true;
+#pragma unroll 1
+        while (__ballot(testing) != 0ull) {
+            int rt;
+            if (r_hi < 0) rt = (r_lo < TEAM_REGU_LINEAR) ? r_lo + 1 : min(2 * r_lo, TEAM_REGU_MAX);
+            else rt = (r_lo + r_hi) / 2;
+            const double coef = regu_coef(rt);
+            double Lr[w - 1];
+#pragma unroll
+            for (int c = 0; c < w - 1; ++c) Lr[c] = (rt == 0) ? Qrow[c] : __builtin_fma(coef, Prow[c], Qrow[c]);
+            const double dg = (rt == 0) ? qdiag : __builtin_fma(coef, pdiag, qdiag);
+            double mqt = maxq;
+            const int neg = team_has_negative_eig(Lr, dg, j, tmask, L + tl::COL, mqt);
+            if (testing) {
+                maxq = mqt;
+                if (alive && neg == 1 && rt < TEAM_REGU_MAX) {
+                    r_lo = rt;
+                } else {
+                    r_hi = rt;
+                    neg_hi = (alive && neg == 1) ? -1 : neg;     // still negative at the cap: 0.1 * 2^r overflowed long ago
+                }
+                testing = (r_hi < 0) || (r_hi - r_lo > 1);
+            }
+        }
+        const int r = r_hi;
+        ok = ok && (neg_hi >= 0);
+        if (alive && r > 0) rs += 1;
+        if (r > 0) {
+            const double coef = regu_coef(r);
+#pragma unroll
+            for (int c = 0; c < w; ++c) Qrow[c] = __builtin_fma(coef, Prow[c], Qrow[c]);
+        }
+        rr += r;
+
+        // ---- gains (:125-129)
+        wave_sync();
+        if (j >= n) {
+#pragma unroll
+            for (int c = 0; c < w; ++c) L[tl::QR + (j - n) * w + c] = Qrow[c];
+        }
+        wave_sync();
+        double Quu[m * m], Qinv[m * m], Qu[m], d[m], Kc[m];
+#pragma unroll
+        for (int aa = 0; aa < m; ++aa) {
+#pragma unroll
+            for (int b = 0; b < m; ++b) Quu[aa * m + b] = L[tl::QR + aa * w + n + b];
+            Qu[aa] = L[tl::QZ + n + aa];
+        }
+        ok = inv_small<m>(Quu, Qinv) && ok;
+#pragma unroll
+        for (int aa = 0; aa < m; ++aa) {
+            double sd = 0.0, sk = 0.0;
+#pragma unroll
+            for (int b = 0; b < m; ++b) {
+                sd += (-Qinv[aa * m + b]) * Qu[b];
+                sk += (-Qinv[aa * m + b]) * L[tl::QR + b * w + (j < n ? j : 0)];
+            }
+            d[aa] = sd;
+            Kc[aa] = sk;
+            if (j < n) L[tl::GB + m + aa * n + j] = sk;
+        }
+        if (j < m) L[tl::GB + j] = d[j];
+        wave_sync();
+        // ---- V_xx, V_x rows (:131-134), expected reduction (:136-137)
+        if (j < n) {
+            double KtQuu[m];
+#pragma unroll
+            for (int b = 0; b < m; ++b) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int aa = 0; aa < m; ++aa) sacc += Kc[aa] * Quu[aa * m + b];
+                KtQuu[b] = sacc;
+            }
+            double Vnew[n];
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+                for (int aa = 0; aa < m; ++aa) t1 += KtQuu[aa] * L[tl::GB + m + aa * n + c];
+#pragma unroll
+                for (int aa = 0; aa < m; ++aa) t2 += Kc[aa] * L[tl::QR + aa * w + c];
+#pragma unroll
+                for (int aa = 0; aa < m; ++aa) t3 += L[tl::QR + aa * w + j] * L[tl::GB + m + aa * n + c];
+                Vnew[c] = ((Qrow[c] + t1) + t2) + t3;
+            }
+            double a1 = 0.0, b1 = 0.0, c1 = 0.0;
+#pragma unroll
+            for (int aa = 0; aa < m; ++aa) a1 += KtQuu[aa] * d[aa];
+#pragma unroll
+            for (int aa = 0; aa < m; ++aa) b1 += Kc[aa] * Qu[aa];
+#pragma unroll
+            for (int aa = 0; aa < m; ++aa) c1 += L[tl::QR + aa * w + j] * d[aa];
+#pragma unroll
+            for (int c = 0; c < n; ++c) L[tl::V + j * n + c] = Vnew[c];      // old V was last read before F was complete
+            L[tl::VX + j] = ((qz + a1) + b1) + c1;
+        }
+        {
+            double ea = 0.0, eb = 0.0;
+#pragma unroll
+            for (int aa = 0; aa < m; ++aa) ea += (-Qu[aa]) * d[aa];
+#pragma unroll
+            for (int aa = 0; aa < m; ++aa) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int b = 0; b < m; ++b) sacc += Quu[b * m + aa] * d[b];
+                eb += (0.5 * d[aa]) * sacc;
+            }
+            redu += ea - eb;
+        }
+        // ---- the stage's G record [d, K] leaves through 13 lanes, 32 bytes each
+        if (j < 13) {
+            const double2* src = reinterpret_cast<const double2*>(L + tl::GB + 4 * j);
+            double2* dst = reinterpret_cast<double2*>(Gp + (long)k * Gss + 4 * j);
+            dst[0] = src[0];
+            dst[1] = src[1];
+        }
+        if (alive && ok) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int aa = 0; aa < m; ++aa) sacc += d[aa] * d[aa];
+            const double nr = sqrt(sacc);
+            anynan = anynan || (nr != nr);
+            best = (nr > best) ? nr : best;
+        }
+    }
+
+    // ---- exit tests and slot allocation, one lane per team (iLQRController.py:43-51)
+    // largest |Q| entry over the team's rows
+#pragma unroll
+    for (int dlt = 1; dlt < TEAM_LANES; dlt *= 2) maxq = fmax(maxq, __shfl_xor(maxq, dlt, TEAM_LANES));
+    const double deltaJ = redu;
+    const double dmax = anynan ? NAN : best;
+    bool need_ls = false, cont = false, finished = false;
+    if (live && j == 0) {
+        a.iters[id] = it;
+        a.maxq[id] = maxq;
+        a.regu_rounds[id] += rr;
+        a.regu_stages[id] += rs;
+        if (ok) {
+            a.dmax[id] = dmax;
+            if (it <= a.trace_len && a.tr_dJ) a.tr_dJ[(long)(it - 1) * a.cap + id] = deltaJ;
+        }
+        if (!ok) {
+            a.status[id] = ILQR_EXIT_LINALG;
+        } else if (deltaJ < 1.0) {                                                    // :50-51
+            a.status[id] = ILQR_EXIT_SMALL_DELTAJ;
+        } else {
+            need_ls = true;
+            a.dJ[s] = deltaJ;
+            cont = (dmax > a.d_tol) && (it < a.max_iter);
+            if (!cont) a.status[id] = (dmax > a.d_tol) ? ILQR_EXIT_MAXITER : ILQR_EXIT_DTOL;
+        }
+        finished = !need_ls;
+    }
+    // a finished trajectory goes to the export buffer: the team copies its records, 16 bytes per lane
+    static_assert(Rec<M>::RT / 2 <= TEAM_LANES, "a T record is copied by one team in one go");
+    if ((__ballot(finished) & tmask) != 0ull && j < Rec<M>::RT / 2) {
+        const Dest<M> out = final_dest<M>(a, id);
+        for (int k = 0; k <= S; ++k) {
+            const double2 v = reinterpret_cast<const double2*>(T.p + (long)k * T.ss)[j];
+            reinterpret_cast<double2*>(out.t + (long)k * out.ts)[j] = v;
+        }
+    }
+    const int jls = wave_append(need_ls, a.cnt + 1);
+    const int ns = wave_append(cont, a.cnt + 0);
+    if (need_ls) {
+        a.ls_slot[jls] = s;
+        a.ls_dest[jls] = cont ? ns : -1;
+        const bool side_by_side = !(a.flags & ILQR_FLAG_LS_SEQUENTIAL) && a.max_ls >= 2 && a.pred[id] != 0;
+        a.ls_from[jls] = side_by_side ? 1 : 2;
+        if (cont) a.idB[ns] = id;
+    }
+}
+
+}  // namespace ilqr

@@ -292,6 +292,13 @@ def _gen_continuous(prefix, xdot, nx, nu, what):
     s, ops["xdot_jac"] = emit_function(f"{prefix}_gen_xdot_jac", ins, [("f", f), ("A", A), ("B", B)],
                                        f"f[{nx}], A = df/dx [{nx}x{nx}], B = df/du [{nx}x{nu}]")
     out += s
+    # directional derivative: one column of [A B] (or any combination of columns) without forming the matrices
+    vx = sp.symbols(f"vx0:{nx}", real=True)
+    vu = sp.symbols(f"vu0:{nu}", real=True)
+    jv = A * sp.Matrix(vx) + B * sp.Matrix(vu)
+    s, ops["xdot_jvp"] = emit_function(f"{prefix}_gen_xdot_jvp", ins + [("vx", vx), ("vu", vu)], [("f", f), ("jv", jv)],
+                                       f"f[{nx}] and the directional derivative jv = (df/dx) vx + (df/du) vu")
+    out += s
     return out, ops, (xs, us)
 
 
