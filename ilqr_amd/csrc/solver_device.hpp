@@ -110,29 +110,56 @@ __device__ inline bool inv_small(const double* A, double* Ainv)
 }
 
 // ------------------------------------------------------------------
-// Symmetric storage.  V_xx and the Q-function Hessian are symmetric in exact
-// arithmetic; the kernels keep their lower triangles only (the reference carries
-// both triangles, which differ by rounding).  Packed lower triangle of a k x k
-// matrix: entry (i, j), i >= j, sits at i (i + 1) / 2 + j.  The full Hessian
-// [[Qxx, Qux'], [Qux, Quu]] is packed in the order [x (n); u (m)].
+// Storage of the stage's matrices.  The reference never symmetrises V_xx or the
+// Q-function Hessian: both triangles are carried and differ by rounding, and in
+// ill-conditioned solves that rounding-level asymmetry decides how many
+// regularisation rounds a stage takes.  So V_xx is kept as the full n x n
+// matrix (row-major), and the Hessian [[Qxx, Qux'], [Qux, Quu]] as
+//   QL  its lower triangle packed by rows: entry (i, j), i >= j, at i (i + 1) / 2 + j, in the order
+//       [x (n); u (m)] -- this is what the PSD test factorises and what holds Qux;
+//   QU  the entries above the diagonal of Qxx (row by row), then those of Quu.
 // ------------------------------------------------------------------
 __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-__device__ __forceinline__ constexpr int sym(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }
+// position in QU of entry (i, j), i < j, of a k x k block whose upper entries start at `base`
+__device__ __forceinline__ constexpr int upp(int k, int i, int j, int base = 0)
+{
+    return base + i * k - i * (i + 1) / 2 + (j - i - 1);
+}
 
 #define ILQR_PRAGMA(x) _Pragma(#x)
 // small plants: every matrix in registers, which needs compile-time indices
-// everywhere (UF = full unroll); 12-state plants keep their loops rolled (UF = 1)
+// everywhere (UF = full unroll)
 #define ILQR_UNROLL ILQR_PRAGMA(unroll UF)
 
+template <int n, int m>
+struct QPack {
+    static constexpr int w = n + m;
+    static constexpr int NL = w * (w + 1) / 2;                      // lower triangle of the full Hessian
+    static constexpr int NUP = n * (n - 1) / 2 + m * (m - 1) / 2;   // upper entries of Qxx and Quu
+    static constexpr int UUB = n * (n - 1) / 2;                     // where Quu's upper entries start in QU
+    // entry (i, j) of Qxx, any i, j
+    __device__ static double qxx(const double* QL, const double* QU, int i, int j)
+    {
+        return i >= j ? QL[tri(i, j)] : QU[upp(n, i, j)];
+    }
+    __device__ static double quu(const double* QL, const double* QU, int a, int b)
+    {
+        return a >= b ? QL[tri(n + a, n + b)] : QU[upp(m, a, b, UUB)];
+    }
+};
+
 // Q-function terms of one stage from the plant's dense stage() derivatives
-// (control/models/model.py:45-53), for symmetric V_xx.  aux = [fx (n*n), fu (n*m)].
+// (control/models/model.py:45-53), in the reference's order of operations:
+// Q_xx = l_xx + (f_x' V_xx) f_x, Q_ux = l_ux + (f_u' V_xx) f_x, Q_uu = l_uu + (f_u' V_xx) f_u.
+// aux = [fx (n*n), fu (n*m)].
 template <class M>
 struct DenseTerms {
     static constexpr int n = M::NDX, m = M::NU, w = n + m;
     static constexpr int AUX = n * n + n * m;
-    static constexpr int UF = M::UNROLL ? 64 : 1;
+    static constexpr int UF = 64;
+    using QP = QPack<n, m>;
     __device__ static void backward_terms(const double* par, const double* x, const double* u, const double* Vx,
-                                          const double* VL, double* Qx, double* Qu, double* QL, double* aux)
+                                          const double* V, double* Qx, double* Qu, double* QL, double* QU, double* aux)
     {
         double lx[n], lu[m], lxx[n * n], lux[m * n], luu[m * m];
         double* const fx = aux;
@@ -160,17 +187,19 @@ struct DenseTerms {
                 for (int j = 0; j < n; ++j) {
                     double s = 0.0;
                     ILQR_UNROLL
-                    for (int t = 0; t < n; ++t) s += fx[t * n + i] * VL[sym(t, j)];
+                    for (int t = 0; t < n; ++t) s += fx[t * n + i] * V[t * n + j];
                     FtV[i * n + j] = s;
                 }
             ILQR_UNROLL
             for (int i = 0; i < n; ++i)
                 ILQR_UNROLL
-                for (int j = 0; j <= i; ++j) {
+                for (int j = 0; j < n; ++j) {
                     double s = 0.0;
                     ILQR_UNROLL
                     for (int t = 0; t < n; ++t) s += FtV[i * n + t] * fx[t * n + j];
-                    QL[tri(i, j)] = lxx[i * n + j] + s;
+                    const double q = lxx[i * n + j] + s;
+                    if (i >= j) QL[tri(i, j)] = q;
+                    else QU[upp(n, i, j)] = q;
                 }
         }
         {
@@ -181,7 +210,7 @@ struct DenseTerms {
                 for (int j = 0; j < n; ++j) {
                     double s = 0.0;
                     ILQR_UNROLL
-                    for (int t = 0; t < n; ++t) s += fu[t * m + i] * VL[sym(t, j)];
+                    for (int t = 0; t < n; ++t) s += fu[t * m + i] * V[t * n + j];
                     GtV[i * n + j] = s;
                 }
             ILQR_UNROLL
@@ -194,11 +223,13 @@ struct DenseTerms {
                     QL[tri(n + i, j)] = lux[i * n + j] + s;
                 }
                 ILQR_UNROLL
-                for (int j = 0; j <= i; ++j) {
+                for (int j = 0; j < m; ++j) {
                     double s = 0.0;
                     ILQR_UNROLL
                     for (int t = 0; t < n; ++t) s += GtV[i * n + t] * fu[t * m + j];
-                    QL[tri(n + i, n + j)] = luu[i * m + j] + s;
+                    const double q = luu[i * m + j] + s;
+                    if (i >= j) QL[tri(n + i, n + j)] = q;
+                    else QU[upp(m, i, j, QP::UUB)] = q;
                 }
             }
         }
@@ -222,14 +253,9 @@ struct DenseTerms {
                 PL[tri(i, j)] = s;
             }
     }
-    __device__ static void final_sym(const double* par, const double* x, double* Vx, double* VL)
+    __device__ static void final_full(const double* par, const double* x, double* Vx, double* V)
     {
-        double Vxx[n * n];
-        M::final(par, x, Vx, Vxx);
-        ILQR_UNROLL
-        for (int i = 0; i < n; ++i)
-            ILQR_UNROLL
-            for (int j = 0; j <= i; ++j) VL[tri(i, j)] = Vxx[i * n + j];
+        M::final(par, x, Vx, V);
     }
 };
 
@@ -238,14 +264,14 @@ struct DenseTerms {
 struct CarSparseTerms {
     static constexpr int AUX = 6;
     __device__ static void backward_terms(const double* par, const double* x, const double* u, const double* Vx,
-                                          const double* VL, double* Qx, double* Qu, double* QL, double* aux)
+                                          const double* V, double* Qx, double* Qu, double* QL, double* QU, double* aux)
     {
-        car_gen_backward_terms(par, x, u, Vx, VL, Qx, Qu, QL, aux);
+        car_gen_backward_terms(par, x, u, Vx, V, Qx, Qu, QL, QU, aux);
     }
     __device__ static void regu_p(const double* aux, double* PL) { car_gen_regu_p(aux, PL); }
-    __device__ static void final_sym(const double* par, const double* x, double* Vx, double* VL)
+    __device__ static void final_full(const double* par, const double* x, double* Vx, double* V)
     {
-        DenseTerms<CarModel>::final_sym(par, x, Vx, VL);
+        car_gen_final(par, x, Vx, V);
     }
 };
 template <class M> struct TermsOf { using type = DenseTerms<M>; };
@@ -335,237 +361,207 @@ constexpr int REGU_GROUPS = 8;    // trajectories per group scan; REGU_GROUPS * 
 // 2^r - 1, the factor of P after r rounds (exact up to r = 53, then 2^r)
 __device__ __forceinline__ double regu_coef(int r) { return ldexp(1.0, r) - 1.0; }
 
+// per-wavefront LDS of the scans, in doubles: Q and P (lower triangles) of up to REGU_GROUPS trajectories
 template <int n, int m>
-struct QPack {
-    static constexpr int w = n + m;
-    static constexpr int NL = w * (w + 1) / 2;
-    static constexpr bool GROUP_SCAN = NL <= 36;
-    // per-wavefront LDS, in doubles: Q and P of up to REGU_GROUPS trajectories (small Hessians) or of the one
-    // trajectory being scanned (big ones)
-    static constexpr int LDS_DOUBLES = (GROUP_SCAN ? REGU_GROUPS : 1) * 2 * NL;
-};
+constexpr int scan_lds_doubles() { return REGU_GROUPS * 2 * QPack<n, m>::NL; }
+// ... followed by what every lane parks there during the PSD tests: Q_x, Q_u and the upper entries of Q
+template <int n, int m>
+constexpr int stage_lds_doubles() { return scan_lds_doubles<n, m>() + 64 * (n + m + QPack<n, m>::NUP); }
 
 // ------------------------------------------------------------------
 // One stage of the backward Riccati sweep: iLQRController.py:103-122 with
 // Model.Q_terms (model.py:45-53), the regularisation loop (:106-115), _gains
 // (:125-129), _V_terms (:131-134) and _expected_cost_reduction (:136-137).
-// Vx and VL (packed V_xx) are updated in place; d_k and K_k are returned.
+// Vx and V (full V_xx) are updated in place; d_k and K_k are returned.
 // Must be called by all 64 lanes of the wavefront together (`alive` = this
-// lane carries a trajectory); `lds` is the wavefront's QPack record.
+// lane carries a trajectory); `lds` holds stage_lds_doubles() doubles.
 // Returns false on the LinAlgError cases.
 // ------------------------------------------------------------------
 template <class M>
-__device__ inline bool backward_stage(const double* par, const double* xk, const double* uk, double* Vx, double* VL,
+__device__ inline bool backward_stage(const double* par, const double* xk, const double* uk, double* Vx, double* V,
                                       double* dk, double* Kk, double& redu, int& regu_rounds, int& regu_stages,
                                       double& maxq, bool alive, double* lds)
 {
     using TR = typename TermsOf<M>::type;
+    using QP = QPack<M::NDX, M::NU>;
     constexpr int n = M::NDX, m = M::NU, w = n + m;
-    constexpr int NL = QPack<n, m>::NL;
-    constexpr int UF = M::UNROLL ? 64 : 1;
-    double Qx[n], Qu[m], QL[NL], aux[TR::AUX];
-    TR::backward_terms(par, xk, uk, Vx, VL, Qx, Qu, QL, aux);
+    constexpr int NL = QP::NL, NUP = QP::NUP;
+    constexpr int UF = 64;
+    double Qx[n], Qu[m], QL[NL], QU[NUP > 0 ? NUP : 1], aux[TR::AUX];
+    TR::backward_terms(par, xk, uk, Vx, V, Qx, Qu, QL, QU, aux);
 
     bool ok = true;
     int r = 0;
     const int lane = threadIdx.x & 63;
-    if constexpr (QPack<n, m>::GROUP_SCAN) {
-        // ---- small Hessians: round-0 test on a copy in every lane, then the wavefront scans
-        double* const ldsP = lds + REGU_GROUPS * NL;                     // P of the published trajectories
-        bool need;
-        {
-            double L[NL];
-            ILQR_UNROLL
-            for (int e = 0; e < NL; ++e) L[e] = QL[e];
-            const int neg = has_negative_eig_packed<w, UF>(L, maxq);
-            ok = ok && (neg >= 0);
-            need = alive && (neg == 1);
-        }
-        if (need) regu_stages += 1;
-        bool stuck_here = false;
+    double* const ldsP = lds + REGU_GROUPS * NL;                     // P of the published trajectories
+    // What is not needed before the gains (Q_x, Q_u, the upper entries of Q) waits in LDS while the PSD
+    // tests run: the factorisations need every register they can get.  Entry e of lane l at park[e * 64 + l].
+    double* const park = lds + scan_lds_doubles<n, m>();
+    ILQR_UNROLL
+    for (int e = 0; e < n; ++e) park[e * 64 + lane] = Qx[e];
+    ILQR_UNROLL
+    for (int e = 0; e < m; ++e) park[(n + e) * 64 + lane] = Qu[e];
+    ILQR_UNROLL
+    for (int e = 0; e < NUP; ++e) park[(w + e) * 64 + lane] = QU[e];
+    // ---- round-0 test on a copy in every lane, then the wavefront scans
+    bool need;
+    {
+        double L[NL];
+        ILQR_UNROLL
+        for (int e = 0; e < NL; ++e) L[e] = QL[e];
+        const int neg = has_negative_eig_packed<w, UF>(L, maxq);
+        ok = ok && (neg >= 0);
+        need = alive && (neg == 1);
+    }
+    if (need) regu_stages += 1;
+    bool stuck_here = false;
 
-        // ---- group scan: rounds 1..REGU_BASE of up to REGU_GROUPS trajectories at once
-        unsigned long long pend = __ballot(need);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const int g = lane / REGU_BASE, c = lane % REGU_BASE;         // this lane tests trajectory g after c + 1 rounds
-        while (pend) {
-            const int rank = __popcll(pend & below);
-            const bool src = need && rank < REGU_GROUPS;
-            const int nsrc = min((int)__popcll(pend), REGU_GROUPS);
-            wave_sync();
-            if (src) {
-                double PL[NL];
-                TR::regu_p(aux, PL);
-                ILQR_UNROLL
-                for (int e = 0; e < NL; ++e) {
-                    lds[rank * NL + e] = QL[e];
-                    ldsP[rank * NL + e] = PL[e];
-                }
-            }
-            wave_sync();
-            int t = 1;
-            double mq = 0.0;
-            if (g < nsrc) {
-                double L[NL];
-                const double coef = regu_coef(c + 1);
-                ILQR_UNROLL
-                for (int e = 0; e < NL; ++e) L[e] = __builtin_fma(coef, ldsP[g * NL + e], lds[g * NL + e]);
-                t = has_negative_eig_packed<w, UF>(L, mq);
-            }
-            // first passing round of every group, its verdict, and the largest |Q| met up to it
-            const unsigned long long passed = __ballot(t != 1);
-            ILQR_UNROLL
-            for (int dlt = 1; dlt < REGU_BASE; dlt *= 2) {
-                const double up = __shfl_up(mq, dlt, REGU_BASE);
-                if (c >= dlt) mq = fmax(mq, up);
-            }
-            const int byte = (int)((passed >> (REGU_BASE * (src ? rank : 0))) & ((1u << REGU_BASE) - 1u));
-            const int cstar = byte ? __ffs(byte) - 1 : -1;
-            const int from = (src ? rank : 0) * REGU_BASE + (cstar >= 0 ? cstar : REGU_BASE - 1);
-            const int tt = __shfl(t, from);
-            const double mqs = __shfl(mq, from);
-            if (src) {
-                maxq = fmax(maxq, mqs);
-                r = (cstar >= 0) ? cstar + 1 : REGU_BASE;
-                if (cstar >= 0) {
-                    const double coef = regu_coef(r);
-                    ILQR_UNROLL
-                    for (int e = 0; e < NL; ++e) QL[e] = __builtin_fma(coef, ldsP[rank * NL + e], QL[e]);
-                    ok = ok && (tt >= 0);
-                } else {
-                    stuck_here = true;
-                }
-                need = false;
-            }
-            pend &= ~__ballot(src);
-        }
-
-        // ---- stuck scan: rounds REGU_BASE + 1, + 2, ... of one trajectory, 64 at a time
-        unsigned long long stuck = __ballot(stuck_here);
-        while (stuck) {
-            const int src = __ffsll((long long)stuck) - 1;
-            stuck &= stuck - 1;
-            wave_sync();
-            if (lane == src) {
-                double PL[NL];
-                TR::regu_p(aux, PL);
-                ILQR_UNROLL
-                for (int e = 0; e < NL; ++e) {
-                    lds[e] = QL[e];
-                    ldsP[e] = PL[e];
-                }
-            }
-            wave_sync();
-            for (int base = REGU_BASE + 1;; base += 64) {
-                const int rc = base + lane;
-                const double coef = regu_coef(rc);
-                double L[NL];
-                ILQR_UNROLL
-                for (int e = 0; e < NL; ++e) L[e] = __builtin_fma(coef, ldsP[e], lds[e]);
-                double mq = 0.0;
-                const int t = has_negative_eig_packed<w, UF>(L, mq);
-                const unsigned long long stops = __ballot(t != 1);
-                if (stops) {
-                    const int win = __ffsll((long long)stops) - 1;
-                    const int tw = __shfl(t, win);
-                    const double mqw = __shfl(mq, win);
-                    if (lane == src) {
-                        r = base + win;
-                        const double cw = regu_coef(r);
-                        ILQR_UNROLL
-                        for (int e = 0; e < NL; ++e) QL[e] = __builtin_fma(cw, ldsP[e], QL[e]);
-                        ok = ok && (tw >= 0);
-                        maxq = fmax(maxq, mqw);
-                    }
-                    break;
-                }
-                if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
-                    if (lane == src) ok = false;
-                    break;
-                }
-            }
-        }
-    } else {
-        // ---- big Hessians: round-0 test on a copy, rounds 1..REGU_BASE lane by lane, then the stuck scan
-        bool need;
-        {
-            double L[NL];
-            for (int e = 0; e < NL; ++e) L[e] = QL[e];
-            const int neg = has_negative_eig_packed<w, UF>(L, maxq);
-            ok = ok && (neg >= 0);
-            need = alive && (neg == 1);
-        }
-        if (need) regu_stages += 1;
-        bool stuck_here = false;
-        if (need) {
+    // ---- group scan: rounds 1..REGU_BASE of up to REGU_GROUPS trajectories at once
+    unsigned long long pend = __ballot(need);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int g = lane / REGU_BASE, c = lane % REGU_BASE;         // this lane tests trajectory g after c + 1 rounds
+    while (pend) {
+        const int rank = __popcll(pend & below);
+        const bool src = need && rank < REGU_GROUPS;
+        const int nsrc = min((int)__popcll(pend), REGU_GROUPS);
+        wave_sync();
+        if (src) {
             double PL[NL];
             TR::regu_p(aux, PL);
-            while (need && r < REGU_BASE) {
-                r += 1;
-                const double coef = regu_coef(r);
-                double L[NL];
-                for (int e = 0; e < NL; ++e) L[e] = __builtin_fma(coef, PL[e], QL[e]);
-                const int neg = has_negative_eig_packed<w, UF>(L, maxq);
-                ok = ok && (neg >= 0);
-                need = (neg == 1);
+            ILQR_UNROLL
+            for (int e = 0; e < NL; ++e) {
+                lds[rank * NL + e] = QL[e];
+                ldsP[rank * NL + e] = PL[e];
             }
-            if (!need) {
-                const double coef = regu_coef(r);
-                for (int e = 0; e < NL; ++e) QL[e] = __builtin_fma(coef, PL[e], QL[e]);
-            }
-            stuck_here = need;
         }
-        unsigned long long stuck = __ballot(stuck_here);
-        while (stuck) {
-            const int src = __ffsll((long long)stuck) - 1;
-            stuck &= stuck - 1;
-            wave_sync();
-            if (lane == src) {
-                double PL[NL];
-                TR::regu_p(aux, PL);
-                for (int e = 0; e < NL; ++e) {
-                    lds[e] = QL[e];
-                    lds[NL + e] = PL[e];
-                }
-            }
-            wave_sync();
-            for (int base = REGU_BASE + 1;; base += 64) {
-                const int rc = base + lane;
-                const double coef = regu_coef(rc);
-                double L[NL];
-                for (int e = 0; e < NL; ++e) L[e] = __builtin_fma(coef, lds[NL + e], lds[e]);
-                double mq = 0.0;
-                const int t = has_negative_eig_packed<w, UF>(L, mq);
-                const unsigned long long stops = __ballot(t != 1);
-                if (stops) {
-                    const int win = __ffsll((long long)stops) - 1;
-                    const int tw = __shfl(t, win);
-                    const double mqw = __shfl(mq, win);
-                    if (lane == src) {
-                        r = base + win;
-                        const double cw = regu_coef(r);
-                        for (int e = 0; e < NL; ++e) QL[e] = __builtin_fma(cw, lds[NL + e], QL[e]);
-                        ok = ok && (tw >= 0);
-                        maxq = fmax(maxq, mqw);
+        wave_sync();
+        int t = 1;
+        double mq = 0.0;
+        if (g < nsrc) {
+            double L[NL];
+            const double coef = regu_coef(c + 1);
+            ILQR_UNROLL
+            for (int e = 0; e < NL; ++e) L[e] = __builtin_fma(coef, ldsP[g * NL + e], lds[g * NL + e]);
+            t = has_negative_eig_packed<w, UF>(L, mq);
+        }
+        // first passing round of every group, its verdict, and the largest |Q| met up to it
+        const unsigned long long passed = __ballot(t != 1);
+        ILQR_UNROLL
+        for (int dlt = 1; dlt < REGU_BASE; dlt *= 2) {
+            const double up = __shfl_up(mq, dlt, REGU_BASE);
+            if (c >= dlt) mq = fmax(mq, up);
+        }
+        const int byte = (int)((passed >> (REGU_BASE * (src ? rank : 0))) & ((1u << REGU_BASE) - 1u));
+        const int cstar = byte ? __ffs(byte) - 1 : -1;
+        const int from = (src ? rank : 0) * REGU_BASE + (cstar >= 0 ? cstar : REGU_BASE - 1);
+        const int tt = __shfl(t, from);
+        const double mqs = __shfl(mq, from);
+        if (src) {
+            maxq = fmax(maxq, mqs);
+            r = (cstar >= 0) ? cstar + 1 : REGU_BASE;
+            if (cstar >= 0) {
+                const double coef = regu_coef(r);
+                const double* const pl = ldsP + rank * NL;
+                ILQR_UNROLL
+                for (int e = 0; e < NL; ++e) QL[e] = __builtin_fma(coef, pl[e], QL[e]);
+                // the parked entries above the diagonal get the mirrored entries of P (P is symmetric)
+                ILQR_UNROLL
+                for (int i = 0; i < n; ++i)
+                    ILQR_UNROLL
+                    for (int j = i + 1; j < n; ++j) {
+                        double* const q = park + (w + upp(n, i, j)) * 64 + lane;
+                        *q = __builtin_fma(coef, pl[tri(j, i)], *q);
                     }
-                    break;
+                ILQR_UNROLL
+                for (int i = 0; i < m; ++i)
+                    ILQR_UNROLL
+                    for (int j = i + 1; j < m; ++j) {
+                        double* const q = park + (w + upp(m, i, j, QP::UUB)) * 64 + lane;
+                        *q = __builtin_fma(coef, pl[tri(n + j, n + i)], *q);
+                    }
+                ok = ok && (tt >= 0);
+            } else {
+                stuck_here = true;      // Q stays as it came: the stuck scan builds every round from it
+            }
+            need = false;
+        }
+        pend &= ~__ballot(src);
+    }
+    
+    // ---- stuck scan: rounds REGU_BASE + 1, + 2, ... of one trajectory, 64 at a time
+    unsigned long long stuck = __ballot(stuck_here);
+    while (stuck) {
+        const int src = __ffsll((long long)stuck) - 1;
+        stuck &= stuck - 1;
+        wave_sync();
+        if (lane == src) {
+            double PL[NL];
+            TR::regu_p(aux, PL);
+            ILQR_UNROLL
+            for (int e = 0; e < NL; ++e) {
+                lds[e] = QL[e];
+                ldsP[e] = PL[e];
+            }
+        }
+        wave_sync();
+        for (int base = REGU_BASE + 1;; base += 64) {
+            const int rc = base + lane;
+            const double coef = regu_coef(rc);
+            double L[NL];
+            ILQR_UNROLL
+            for (int e = 0; e < NL; ++e) L[e] = __builtin_fma(coef, ldsP[e], lds[e]);
+            double mq = 0.0;
+            const int t = has_negative_eig_packed<w, UF>(L, mq);
+            const unsigned long long stops = __ballot(t != 1);
+            if (stops) {
+                const int win = __ffsll((long long)stops) - 1;
+                const int tw = __shfl(t, win);
+                const double mqw = __shfl(mq, win);
+                if (lane == src) {
+                    r = base + win;
+                    const double cw = regu_coef(r);
+                    ILQR_UNROLL
+                    for (int e = 0; e < NL; ++e) QL[e] = __builtin_fma(cw, ldsP[e], QL[e]);
+                    ILQR_UNROLL
+                    for (int i = 0; i < n; ++i)
+                        ILQR_UNROLL
+                        for (int j = i + 1; j < n; ++j) {
+                            double* const q = park + (w + upp(n, i, j)) * 64 + lane;
+                            *q = __builtin_fma(cw, ldsP[tri(j, i)], *q);
+                        }
+                    ILQR_UNROLL
+                    for (int i = 0; i < m; ++i)
+                        ILQR_UNROLL
+                        for (int j = i + 1; j < m; ++j) {
+                            double* const q = park + (w + upp(m, i, j, QP::UUB)) * 64 + lane;
+                            *q = __builtin_fma(cw, ldsP[tri(n + j, n + i)], *q);
+                        }
+                    ok = ok && (tw >= 0);
+                    maxq = fmax(maxq, mqw);
                 }
-                if (base > 1200) {
-                    if (lane == src) ok = false;
-                    break;
-                }
+                break;
+            }
+            if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
+                if (lane == src) ok = false;
+                break;
             }
         }
     }
     regu_rounds += r;
     if (!ok) return false;
+    ILQR_UNROLL
+    for (int e = 0; e < n; ++e) Qx[e] = park[e * 64 + lane];
+    ILQR_UNROLL
+    for (int e = 0; e < m; ++e) Qu[e] = park[(n + e) * 64 + lane];
+    ILQR_UNROLL
+    for (int e = 0; e < NUP; ++e) QU[e] = park[(w + e) * 64 + lane];
 
     // ---- gains (iLQRController.py:125-129): d = -Quu^-1 Qu, K = -Quu^-1 Qux
     double Quu[m * m], Qinv[m * m];
     ILQR_UNROLL
     for (int a = 0; a < m; ++a)
         ILQR_UNROLL
-        for (int b = 0; b < m; ++b) Quu[a * m + b] = QL[sym(n + a, n + b)];
+        for (int b = 0; b < m; ++b) Quu[a * m + b] = QP::quu(QL, QU, a, b);
     if (!inv_small<m>(Quu, Qinv)) return false;
     ILQR_UNROLL
     for (int a = 0; a < m; ++a) {
@@ -596,7 +592,7 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
     ILQR_UNROLL
     for (int i = 0; i < n; ++i) {
         ILQR_UNROLL
-        for (int j = 0; j <= i; ++j) {
+        for (int j = 0; j < n; ++j) {
             double t1 = 0.0, t2 = 0.0, t3 = 0.0;
             ILQR_UNROLL
             for (int a = 0; a < m; ++a) t1 += KtQuu[i * m + a] * Kk[a * n + j];
@@ -604,7 +600,7 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
             for (int a = 0; a < m; ++a) t2 += Kk[a * n + i] * QL[tri(n + a, j)];
             ILQR_UNROLL
             for (int a = 0; a < m; ++a) t3 += QL[tri(n + a, i)] * Kk[a * n + j];
-            VL[tri(i, j)] = ((QL[tri(i, j)] + t1) + t2) + t3;
+            V[i * n + j] = ((QP::qxx(QL, QU, i, j) + t1) + t2) + t3;
         }
         double a1 = 0.0, b1 = 0.0, c1 = 0.0;
         ILQR_UNROLL
@@ -735,23 +731,20 @@ __device__ inline bool backward_pass(const double* par, const RecIn& T, const Re
 {
     using TR = typename TermsOf<M>::type;
     constexpr int n = M::NDX, m = M::NU, nx = M::NX;
-    double Vx[n], VL[n * (n + 1) / 2], xu[nx + m], nxt[nx + m], g[m + m * n];
+    double Vx[n], V[n * n], xu[nx + m], g[m + m * n];
     double* const dk = g;
     double* const Kk = g + m;
     load_rec<nx>(T.p + (long)S * T.ss, xu);
-    load_rec<nx + m>(T.p + (long)(S - 1) * T.ss, nxt);
-    TR::final_sym(par, xu, Vx, VL);
+    TR::final_full(par, xu, Vx, V);
     double redu = 0.0, best = -INFINITY;
     bool anynan = false, ok = true;
     // Nothing may still be in flight when the loop is entered: otherwise the wait-count bookkeeping of the
     // loop has to allow for these loads on every trip and ends up waiting for the previous stage's stores.
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
     for (int k = S - 1; k >= 0; --k) {
-        for (int i = 0; i < nx + m; ++i) xu[i] = nxt[i];
-        // the record of the next stage to be processed travels while this one is worked on
-        load_rec<nx + m>(T.p + (long)(k > 0 ? k - 1 : 0) * T.ss, nxt);
+        load_rec<nx + m>(T.p + (long)k * T.ss, xu);
         const bool alive = active && ok;
-        const bool good = backward_stage<M>(par, xu, xu + nx, Vx, VL, dk, Kk, redu, regu_rounds, regu_stages, maxq,
+        const bool good = backward_stage<M>(par, xu, xu + nx, Vx, V, dk, Kk, redu, regu_rounds, regu_stages, maxq,
                                             alive, lds);
         ok = ok && good;
         // stored by every lane, whatever its state (a lane without a trajectory is given a scratch record by

@@ -67,10 +67,8 @@ enum {
     ILQR_FLAG_PARALLEL_LS = 1,   /* sixteen at a time right after alpha = 1 was rejected */
     ILQR_FLAG_LS_SEQUENTIAL = 2, /* never side by side: one launch per candidate (max_ls <= 60) */
     ILQR_FLAG_TIMING = 4,        /* bracket every kernel launch with HIP events: see ilqr_last_timing() */
-    ILQR_FLAG_SINGLE_STREAM = 8, /* run everything on the caller's stream (default: large batches are cut into
+    ILQR_FLAG_SINGLE_STREAM = 8  /* run everything on the caller's stream (default: large batches are cut into
                                     parts that run concurrently on internal streams, one host thread each) */
-    ILQR_FLAG_LANE_BACKWARD = 16 /* 12-state plants: backward pass with one lane per trajectory instead of a
-                                    team of 16 lanes (the slow variant, kept for cross-checking) */
 };
 
 /* Kernel phases of ilqr_solve_batch, for ilqr_timing. */

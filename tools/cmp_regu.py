@@ -25,7 +25,7 @@ for kind in ("quad_quat", "quad_ea", "acrobot"):
         x0 = np.column_stack([rng.uniform(-np.pi, np.pi, B), rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B), rng.uniform(-1, 1, B)])
         u0 = rng.standard_normal((B, N - 1, 1))
     ref = co.solve_batch(kind, par, N, mi, ml, dt, x0, u0)["info"]
-    for flags in (0, _lib.FLAG_LANE_BACKWARD):
+    for flags in (0,):
         r = BatchSolver(mid, par, N, mi, ml, dt, flags=flags).solve(x0, u0)
         print(kind, "flags", flags, "gpu mean regu %.1f" % r.regu_rounds.double().mean().item(), "oracle %.1f" % ref["regu_rounds"].mean(),
               "status gpu", torch.bincount(r.status, minlength=4).cpu().tolist(), "oracle", np.bincount(ref["status"], minlength=4).tolist(),

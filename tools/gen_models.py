@@ -228,15 +228,15 @@ def gen_car():
     s, ops["final"] = emit_function("car_gen_final", ins[:2], [("V_x", lfx), ("V_xx", lfx.jacobian(xs))],
                                     "final-cost derivatives (car.py:46-52)")
     out += s
-    # ---- backward-stage terms on symmetric (packed lower triangle) storage, sparsity folded in by SymPy
+    # ---- backward-stage terms, sparsity of f_x, f_u, l_xx folded in by SymPy.  V_xx comes in as the full
+    # (not exactly symmetric) matrix the reference carries, and both triangles of Q_xx and Q_uu go out:
+    # the reference never symmetrises, and the rounding-level asymmetry decides how ill-conditioned solves
+    # regularise.
     n, m = 5, 2
     w = n + m
     Vx = sp.symbols("Vx0:5", real=True)
-    VLs = sp.symbols("VL0:15", real=True)
-    V = sp.zeros(n, n)
-    for i in range(n):
-        for j in range(i + 1):
-            V[i, j] = V[j, i] = VLs[i * (i + 1) // 2 + j]
+    Vs = sp.symbols("V0:25", real=True)
+    V = sp.Matrix(n, n, lambda i, j: Vs[i * n + j])
     fx = f.jacobian(xs)
     fu = f.jacobian(us)
     # name the six state-dependent entries of f_x so that products are formed from them, not re-derived
@@ -246,12 +246,14 @@ def gen_car():
     for k, (i, j) in enumerate(fa_pos):
         fxs[i, j] = fa[k]
     assert all(fxs[i, j].is_number or fxs[i, j] in fa for i in range(n) for j in range(n))
-    Wm = V * fxs                                  # V f_x
-    Ws = sp.Matrix(n, n, lambda i, j: sp.Symbol(f"W{i}{j}", real=True))
+    Sm = fxs.T * V                                # f_x' V_xx first, as model.py:50 evaluates left to right
+    Tm = fu.T * V                                 # f_u' V_xx
+    Ss = sp.Matrix(n, n, lambda i, j: sp.Symbol(f"S{i}{j}", real=True))
+    Ts = sp.Matrix(m, n, lambda i, j: sp.Symbol(f"T{i}{j}", real=True))
     lxx = lx.jacobian(xs)
-    Qxx = lxx + fxs.T * Ws
-    Qux = lu.jacobian(xs) + fu.T * Ws
-    Quu = lu.jacobian(us) + fu.T * V * fu
+    Qxx = lxx + Ss * fxs
+    Qux = lu.jacobian(xs) + Ts * fxs
+    Quu = lu.jacobian(us) + Ts * fu
     Qx_e = lx.T + fxs.T * sp.Matrix(Vx)
     Qu_e = lu.T + fu.T * sp.Matrix(Vx)
     full = sp.zeros(w, w)
@@ -259,14 +261,16 @@ def gen_car():
     full[n:, :n] = Qux
     full[n:, n:] = Quu
     QL = [full[i, j] for i in range(w) for j in range(i + 1)]
-    # substitute: fa_k and W_ij are emitted as temporaries first
+    QU = [Qxx[i, j] for i in range(n) for j in range(i + 1, n)] + [Quu[i, j] for i in range(m) for j in range(i + 1, m)]
     pre = [(fa[k], fx[i, j]) for k, (i, j) in enumerate(fa_pos)] + \
-          [(Ws[i, j], Wm[i, j]) for i in range(n) for j in range(n)]
+          [(Ss[i, j], Sm[i, j]) for i in range(n) for j in range(n)] + \
+          [(Ts[i, j], Tm[i, j]) for i in range(m) for j in range(n)]
     s, ops["backward_terms"] = emit_function(
-        "car_gen_backward_terms", [("p", ps), ("x", xs), ("u", us), ("Vx", Vx), ("VL", VLs)],
-        [("Qx", Qx_e), ("Qu", Qu_e), ("QL", QL), ("fa", list(fa))],
-        "Q-function terms of one backward stage (control/models/model.py:45-53) for symmetric V_xx: "
-        "Qx[5], Qu[2], QL[28] = packed lower triangle of [[Qxx, Qux'], [Qux, Quu]], fa[6] = the state-dependent "
+        "car_gen_backward_terms", [("p", ps), ("x", xs), ("u", us), ("Vx", Vx), ("V", Vs)],
+        [("Qx", Qx_e), ("Qu", Qu_e), ("QL", QL), ("QU", QU), ("fa", list(fa))],
+        "Q-function terms of one backward stage (control/models/model.py:45-53) from the full V_xx [5x5]: "
+        "Qx[5], Qu[2], QL[28] = lower triangle (packed by rows) of [[Qxx, Qux'], [Qux, Quu]], QU[11] = the entries "
+        "above the diagonal of Qxx (row by row) and of Quu, fa[6] = the state-dependent "
         "entries (0,2) (0,3) (1,2) (1,3) (2,3) (2,4) of f_x", pre=pre)
     out += s
     Fm = sp.Matrix(n, w, lambda i, j: fxs[i, j] if j < n else fu[i, j - n])
