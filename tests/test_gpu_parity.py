@@ -373,3 +373,25 @@ def test_ill_conditioned_regime_matches_checker_statistically(torch_gpu, oracle,
     ratio = got["regu"].mean() / ref["regu_rounds"].mean()
     assert 0.8 < ratio < 1.25, ratio
     assert (got["iters"] == ref["iters"]).mean() > 0.85
+
+
+def test_car_population_statistics_match_checker(torch_gpu, oracle):
+    """Headline batch, all trajectories (a quarter of them are ill conditioned and not reproducible one by one):
+    well-conditioned solves agree decision for decision, and the population as a whole exits for the same
+    reasons, regularises as much and iterates as long as the checker's."""
+    rng = np.random.default_rng(1234)
+    B = 4096
+    c = _cfg(oracle, "car")
+    x0, u0 = _car_box(rng, B), rng.standard_normal((B, 39, 2)) * 1e-4
+    got = _solve(c, x0, u0)
+    ref = oracle.solve_batch("car", c["par"], 40, 50, 20, 1e-3, x0, u0)["info"]
+    calm = ref["max_abs_q"] < 1e5
+    assert calm.mean() > 0.6
+    assert np.array_equal(got["iters"][calm], ref["iters"][calm])
+    assert np.array_equal(got["regu"][calm], ref["regu_rounds"][calm])
+    assert np.array_equal(got["status"][calm], ref["status"][calm])
+    hg, hr = np.bincount(got["status"], minlength=4), np.bincount(ref["status"], minlength=4)
+    assert np.abs(hg - hr).max() <= B // 64, (hg, hr)
+    assert 0.9 < got["regu"].mean() / ref["regu_rounds"].mean() < 1.1
+    assert abs(got["iters"].mean() - ref["iters"].mean()) < 0.15
+    assert (got["iters"] == ref["iters"]).mean() > 0.95
