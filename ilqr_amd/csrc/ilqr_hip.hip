@@ -243,7 +243,7 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
         return tm.finish(0, tout);
     }
     // Line-search schedule after evaluation 1 (all three give bit-identical results):
-    //   default                  evaluations 2..5 four lanes per trajectory, then 6.. sixteen at a time, commit
+    //   default                  the next GA evaluations GA lanes per trajectory, then GB at a time, commit
     //   ILQR_FLAG_PARALLEL_LS    evaluations 2.. sixteen at a time, commit
     //   ILQR_FLAG_LS_SEQUENTIAL  one launch per evaluation over the compacted list of those still searching
     constexpr int GA = 8, GB = 16;

@@ -11,8 +11,8 @@
 //   init      rollout + cost of the initial guess            (:27-34)
 //   backward  Riccati sweep, exit tests, slot allocation      (:43-51, :98-123)
 //   forward1  first line-search candidate, alpha = 1, written (:60-68, :87-96)
-//   group<4>  candidates 2..5 of the rejected ones side by side, cost only
-//   group<16> candidates 6.. of those still searching, 16 at a time, cost only
+//   group<8>  the next 8 candidates of the rejected ones side by side, cost only
+//   group<16> further candidates of those still searching, 16 at a time, cost only
 //   commit    the candidate each backtracking search stopped at is written (:66-72)
 //   export    finished trajectories, record layout -> the caller's strided arrays (:84)
 //

@@ -59,9 +59,10 @@ typedef struct {
 } ilqr_problem;
 
 /* Line-search evaluation schedule (the result does not depend on it, bit for bit):
- * default: candidate 1 (alpha = 1) for every trajectory; for those it was rejected for, candidates 2..5 in four
- * neighbouring lanes, then candidates 6.. sixteen at a time (cost only, the first one at which the reference's
- * loop would stop wins), then one pass that writes the trajectory each search ended with. */
+ * default: candidate 1 (alpha = 1) computed and written for every trajectory, except those whose previous search
+ * rejected it; for the rejected and the excepted ones the next eight candidates in eight neighbouring lanes, then
+ * sixteen at a time (cost only; the first one at which the reference's loop would stop wins), then one pass that
+ * writes the trajectory each search ended with. */
 enum {
     ILQR_FLAG_NONE = 0,
     ILQR_FLAG_PARALLEL_LS = 1,   /* sixteen at a time right after alpha = 1 was rejected */
