@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ILQR_HIP_LIB") or os.path.join(_HERE, "lib", "libilqr_hip.so")   # override: A/B builds
 
-MODEL_CAR, MODEL_ACROBOT, MODEL_QUAD_EA, MODEL_QUAD_QUAT = 0, 1, 2, 3
+MODEL_CAR, MODEL_ACROBOT, MODEL_QUAD_EA, MODEL_QUAD_QUAT, MODEL_USER = 0, 1, 2, 3, 4
 EXIT_DTOL, EXIT_SMALL_DELTAJ, EXIT_MAXITER, EXIT_LINALG = 0, 1, 2, 3
 EXIT_NAMES = {0: "d_tol", 1: "deltaJ<1", 2: "max_iter", 3: "linalg_error"}
 FLAG_PARALLEL_LS = 1
@@ -46,19 +46,19 @@ class LibraryMissing(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    """Load libilqr_hip.so (once).  Raises LibraryMissing when it is not built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def lib(path=None):
+    """Load a solver library (once per path; default libilqr_hip.so).  Raises LibraryMissing when it is not built."""
+    path = os.path.abspath(path or LIB_PATH)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise LibraryMissing(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     L.ilqr_model_info.restype = C.c_int
     L.ilqr_model_info.argtypes = [C.c_int32] + [C.POINTER(C.c_int32)] * 4
     L.ilqr_workspace_bytes.restype = C.c_size_t
@@ -75,16 +75,17 @@ def lib():
     L.ilqr_last_timing.argtypes = [C.POINTER(Timing)]
     L.ilqr_last_error.restype = C.c_char_p
     L.ilqr_version.restype = C.c_char_p
-    _lib = L
+    _libs[path] = L
     return L
 
 
-def check(rc: int):
+def check(rc: int, L=None):
     if rc != 0:
-        raise RuntimeError(f"libilqr_hip error {rc}: {lib().ilqr_last_error().decode()}")
+        raise RuntimeError(f"libilqr_hip error {rc}: {(L or lib()).ilqr_last_error().decode()}")
 
 
-def model_info(model_id: int):
+def model_info(model_id: int, L=None):
+    L = L or lib()
     v = [C.c_int32() for _ in range(4)]
-    check(lib().ilqr_model_info(model_id, *[C.byref(x) for x in v]))
+    check(L.ilqr_model_info(model_id, *[C.byref(x) for x in v]), L)
     return tuple(x.value for x in v)

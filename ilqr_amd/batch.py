@@ -47,10 +47,11 @@ class BatchResult:
 
 class BatchSolver:
     def __init__(self, model_id: int, params, N: int, max_iter: int, max_linesearch_iters: int = 20,
-                 d_tol: float = 1e-3, device="cuda:0", trace_len: int = 0, flags: int = 0):
-        self.lib = _lib.lib()
+                 d_tol: float = 1e-3, device="cuda:0", trace_len: int = 0, flags: int = 0, library=None):
+        # library: path of a solver library built for a user-defined plant (ilqr_amd.models.user); default built-ins
+        self.lib = _lib.lib(library)
         self.model_id = int(model_id)
-        self.nx, self.nu, self.ndx, self.npar = _lib.model_info(self.model_id)
+        self.nx, self.nu, self.ndx, self.npar = _lib.model_info(self.model_id, self.lib)
         self.N, self.max_iter, self.max_ls, self.d_tol = int(N), int(max_iter), int(max_linesearch_iters), float(d_tol)
         if self.N < 2:
             raise ValueError("N must be >= 2")
@@ -61,6 +62,9 @@ class BatchSolver:
         self.flags = int(flags)
         self.set_params(params)
         self._ws = None
+
+    def _check(self, rc):
+        _lib.check(rc, self.lib)
 
     # ------------------------------------------------------------ parameters
     def set_params(self, params):
@@ -124,7 +128,7 @@ class BatchSolver:
         nbytes = int(self.lib.ilqr_workspace_bytes(C.byref(pr)))
         ws = self._workspace(nbytes)
         oo = _lib.Outputs(*[_ptr(out.get(k)) for k, _ in _lib.Outputs._fields_])
-        _lib.check(self.lib.ilqr_solve_batch(C.byref(pr), _ptr(x0), _ptr(u), _ptr(x), C.byref(oo), _ptr(ws),
+        self._check(self.lib.ilqr_solve_batch(C.byref(pr), _ptr(x0), _ptr(u), _ptr(x), C.byref(oo), _ptr(ws),
                                              ws.numel(), self._stream()))
         return x, u, out
 
@@ -132,7 +136,7 @@ class BatchSolver:
         """Device time per kernel phase of this thread's last solve made with FLAG_TIMING:
         {phase: (milliseconds, launches)} plus "iterations"."""
         t = _lib.Timing()
-        _lib.check(self.lib.ilqr_last_timing(C.byref(t)))
+        self._check(self.lib.ilqr_last_timing(C.byref(t)))
         d = {name: (float(t.ms[i]), int(t.launches[i])) for i, name in enumerate(_lib.PHASES)}
         d["iterations"] = int(t.iterations)
         return d
@@ -165,7 +169,7 @@ class BatchSolver:
         xs = torch.empty((self.N, self.nx, B), dtype=torch.float64, device=self.device)
         J = torch.empty(B, dtype=torch.float64, device=self.device)
         pr = self._problem(B, B)
-        _lib.check(self.lib.ilqr_rollout_cost(C.byref(pr), _ptr(x0s), _ptr(us), _ptr(xs), _ptr(J), self._stream()))
+        self._check(self.lib.ilqr_rollout_cost(C.byref(pr), _ptr(x0s), _ptr(us), _ptr(xs), _ptr(J), self._stream()))
         return xs.permute(2, 0, 1).contiguous(), J
 
     def model_eval(self, xs, us, what=("xn", "cs", "cf", "l_x", "l_u", "l_xx", "l_ux", "l_uu", "f_x", "f_u",
@@ -182,7 +186,7 @@ class BatchSolver:
         order = ("xn", "cs", "cf", "l_x", "l_u", "l_xx", "l_ux", "l_uu", "f_x", "f_u", "V_x", "V_xx")
         pr = self._problem(B, B)
         xs_soa, us_soa = xd.t().contiguous(), ud.t().contiguous()   # named: must outlive the launch
-        _lib.check(self.lib.ilqr_model_eval(C.byref(pr), _ptr(xs_soa), _ptr(us_soa),
+        self._check(self.lib.ilqr_model_eval(C.byref(pr), _ptr(xs_soa), _ptr(us_soa),
                                             *[_ptr(bufs.get(k)) for k in order], self._stream()))
         return {k: bufs[k].t().reshape((B,) + shapes[k]) for k in what}
 
@@ -190,4 +194,4 @@ class BatchSolver:
         """In place on SoA buffers: x0 <- f(x0, u[0]); u[:-1] <- u[1:]."""
         stride = x0_soa.shape[-1]
         pr = self._problem(stride if B is None else B, stride)
-        _lib.check(self.lib.ilqr_mpc_advance(C.byref(pr), _ptr(x0_soa), _ptr(u_soa), self._stream()))
+        self._check(self.lib.ilqr_mpc_advance(C.byref(pr), _ptr(x0_soa), _ptr(u_soa), self._stream()))

@@ -1,0 +1,273 @@
+"""SymPy expressions -> straight-line C for host and gfx950 device, and plant models defined by the user.
+
+The reference obtains plant derivatives from symbolic back-ends at run time
+(pydrake.symbolic in control/models/car.py:5-52, CasADi elsewhere) and lets a
+user define a plant by writing `discrete_dynamics`, `_cost_stage`, `_cost_final`
+in Python (README.md:25-31).  Here the same expressions are differentiated once,
+common sub-expressions are eliminated and the result is printed as plain C
+functions (`ILQR_HD static inline`, where ILQR_HD is `__host__ __device__` under
+hipcc and nothing under gcc).  `tools/gen_models.py` uses this for the four
+shipped plants; `generate_user_header` / `build_user_library` use it for a plant
+the user writes with the math namespace `ilqr_amd.sym`: the functions are run once
+on SymPy symbols, the solver is compiled for that plant with hipcc, and the
+resulting shared library is loaded like the built-in one.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+import time
+
+import sympy as sp
+from sympy.printing.c import C99CodePrinter
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared"]
+VERBOSE = False
+MAX_USER_W = 8        # nx + nu the lane-per-trajectory backward stage is built for (everything in registers)
+
+
+class _Printer(C99CodePrinter):
+    """C printer that never calls pow() for the small rational powers that occur."""
+
+    def _print_Pow(self, expr):
+        b, e = expr.base, expr.exp
+        if e.is_Integer:
+            n = int(e)
+            bs = self.parenthesize(b, 1000)
+            if n == 0:
+                return "1.0"
+            mul = "*".join([bs] * abs(n))
+            return f"({mul})" if n > 0 else f"(1.0/({mul}))"
+        if e.is_Rational and e.q == 2:
+            n = int(e.p)
+            bs = self._print(b)
+            root = f"sqrt({bs})"
+            k = abs(n)
+            # b^(k/2) = b^(k//2) * sqrt(b) for odd k
+            pw = "*".join([f"({bs})"] * (k // 2) + [root])
+            return f"({pw})" if n > 0 else f"(1.0/({pw}))"
+        return super()._print_Pow(expr)
+
+    def _print_Rational(self, expr):
+        return f"({float(expr.p)!r}/{float(expr.q)!r})"
+
+    def _print_Integer(self, expr):
+        return f"{float(int(expr))!r}"
+
+    def _print_Float(self, expr):
+        return repr(float(expr))
+
+
+_P = _Printer()
+
+
+def _count_ops(exprs):
+    """Count arithmetic in a list of (already CSE'd) expressions.
+    FMA-able mul+add pairs are counted as separate mul and add (2 flops)."""
+    c = dict(add=0, mul=0, div=0, sqrt=0, sin=0, cos=0, tan=0)
+    for e in exprs:
+        for node in sp.preorder_traversal(e):
+            if isinstance(node, sp.Add):
+                c["add"] += len(node.args) - 1
+            elif isinstance(node, sp.Mul):
+                nargs = len(node.args)
+                # a*b**-1 is a division
+                ndiv = sum(1 for a in node.args if isinstance(a, sp.Pow) and a.exp.is_negative)
+                c["mul"] += max(nargs - 1 - ndiv, 0)
+                c["div"] += ndiv
+            elif isinstance(node, sp.Pow):
+                ex = node.exp
+                if ex.is_Integer:
+                    c["mul"] += abs(int(ex)) - 1
+                    # a lone reciprocal (not inside a Mul) is handled by the Mul case mostly
+                elif ex.is_Rational and ex.q == 2:
+                    c["sqrt"] += 1
+                    c["mul"] += abs(int(ex.p)) // 2
+            elif isinstance(node, sp.sin):
+                c["sin"] += 1
+            elif isinstance(node, sp.cos):
+                c["cos"] += 1
+            elif isinstance(node, sp.tan):
+                c["tan"] += 1
+    c["flops"] = sum(c.values())
+    return c
+
+
+def emit_function(name, inputs, outputs, doc, pre=None):
+    """inputs: list of (cname, [symbols]); outputs: list of (cname, sympy Matrix or list).
+    Dense row-major outputs; structural zeros are written as 0.0.
+    pre: optional list of (symbol, expression) evaluated first, in order, as named temporaries."""
+    flat = []
+    for _, M in outputs:
+        M = sp.Matrix(M)
+        flat.extend(list(M))          # row-major
+    pre = pre or []
+    npre = len(pre)
+    flat = [e for _, e in pre] + flat
+    t0 = time.time()
+    # sin(a) and cos(a) of the same argument share one range reduction: both come from one ILQR_SINCOS
+    kinds = {}
+    for e in flat:
+        for node in sp.preorder_traversal(e):
+            if isinstance(node, (sp.sin, sp.cos)):
+                kinds.setdefault(node.args[0], set()).add(type(node))
+    pairs = [a for a, k in kinds.items() if k == {sp.sin, sp.cos} and not a.has(sp.sin, sp.cos, sp.tan)]
+    pairs.sort(key=str)
+    sc = {a: (sp.Symbol(f"sn{i}"), sp.Symbol(f"cs{i}")) for i, a in enumerate(pairs)}
+    if sc:
+        rep = {}
+        for a, (S, Cc) in sc.items():
+            rep[sp.sin(a)] = S
+            rep[sp.cos(a)] = Cc
+        flat = [e.xreplace(rep) for e in flat]
+    repl, red = sp.cse(flat, symbols=sp.numbered_symbols("t"), optimizations="basic", order="none")
+    lines = []
+    args = ", ".join([f"const double* __restrict__ {n}" for n, _ in inputs] +
+                     [f"double* __restrict__ {n}" for n, _ in outputs])
+    lines.append(f"/* {doc} */")
+    lines.append(f"ILQR_HD static inline void {name}({args})")
+    lines.append("{")
+    sub = {}
+    for n, syms in inputs:
+        for i, s in enumerate(syms):
+            sub[s] = sp.Symbol(f"{n}[{i}]")
+    used = set()
+    for e in [r for _, r in repl] + red:
+        used |= e.free_symbols
+    for n, syms in inputs:
+        if not any(s in used for s in syms):
+            lines.append(f"    (void){n};")
+    for a in pairs:
+        S, Cc = sc[a]
+        lines.append(f"    double {S}, {Cc};")
+        lines.append(f"    ILQR_SINCOS({_P.doprint(a.xreplace(sub))}, {S}, {Cc});")
+    for t, e in repl:
+        lines.append(f"    const double {t} = {_P.doprint(e.xreplace(sub))};")
+    for k in range(npre):
+        lines.append(f"    const double {pre[k][0]} = {_P.doprint(red[k].xreplace(sub))};")
+    red = red[npre:]
+    k = 0
+    for n, M in outputs:
+        M = sp.Matrix(M)
+        for i in range(len(M)):
+            lines.append(f"    {n}[{i}] = {_P.doprint(red[k].xreplace(sub))};")
+            k += 1
+    lines.append("}")
+    ops = _count_ops([e for _, e in repl] + red)
+    ops["sin"] += len(pairs); ops["cos"] += len(pairs); ops["flops"] += 2 * len(pairs)
+    if VERBOSE:
+        sys.stderr.write(f"  {name}: {len(repl)} temporaries, {ops['flops']} flops, cse {time.time() - t0:.1f}s\n")
+    return "\n".join(lines) + "\n", ops
+
+
+HEADER = """/* GENERATED by tools/gen_models.py -- do not edit.
+ * {what}
+ * Dense row-major outputs.  ILQR_HD = __host__ __device__ under hipcc.
+ */
+#pragma once
+#include <math.h>
+#ifndef ILQR_HD
+#  if defined(__HIPCC__)
+#    define ILQR_HD __host__ __device__
+#  else
+#    define ILQR_HD
+#  endif
+#endif
+/* sine and cosine of one argument: one shared range reduction on the GPU */
+#ifndef ILQR_SINCOS
+#  if defined(__HIP_DEVICE_COMPILE__)
+#    define ILQR_SINCOS(a, s, c) sincos((a), &(s), &(c))
+#  else
+#    define ILQR_SINCOS(a, s, c) ((s) = sin(a), (c) = cos(a))
+#  endif
+#endif
+
+"""
+
+
+
+
+# ---------------------------------------------------------------------------
+# plants defined by the user
+# ---------------------------------------------------------------------------
+def user_expressions(nx, nu, n_par, dynamics, cost_stage, cost_final):
+    """Run the user's functions once on SymPy symbols: dynamics(x, u, p), cost_stage(x, u, p), cost_final(x, p).
+    Returns (xs, us, ps, f [nx], l, lf)."""
+    if nx + nu > MAX_USER_W:
+        raise NotImplementedError(
+            f"nx + nu = {nx + nu} > {MAX_USER_W}: the backward stage for user plants keeps every matrix in registers")
+    import numpy as np
+    xs = sp.symbols(f"x0:{nx}", real=True)
+    us = sp.symbols(f"u0:{nu}", real=True)
+    ps = sp.symbols(f"p0:{max(1, n_par)}", real=True)
+    x = np.array(xs, dtype=object)
+    u = np.array(us, dtype=object)
+    p = np.array(ps[:n_par], dtype=object)
+    f = sp.Matrix([sp.sympify(e) for e in np.asarray(dynamics(x, u, p), dtype=object).ravel()])
+    if f.shape[0] != nx:
+        raise ValueError(f"discrete_dynamics returned {f.shape[0]} components, expected nx = {nx}")
+    l = sp.sympify(cost_stage(x, u, p))
+    lf = sp.sympify(cost_final(x, p))
+    return xs, us, ps, f, l, lf
+
+
+CODEGEN_VERSION = "1"   # part of the library key: bump when the printed C or the solver sources change meaning
+
+
+def user_key(nx, nu, n_par, exprs):
+    """Identity of a traced plant: dimensions and the canonical text of its three expressions."""
+    xs, us, ps, f, l, lf = exprs
+    text = "|".join([CODEGEN_VERSION, str(nx), str(nu), str(n_par), sp.srepr(f), sp.srepr(l), sp.srepr(lf)])
+    return hashlib.sha256(text.encode()).hexdigest()[:12]
+
+
+def generate_user_header(nx, nu, n_par, exprs, name="user"):
+    """C text of user_gen.h: USER_NX / USER_NU / USER_NP and user_gen_{dynamics,cost_stage,cost_final,stage,final}
+    with the signatures of the car's generated functions."""
+    xs, us, ps, f, l, lf = exprs
+    lx = sp.Matrix([l]).jacobian(xs)
+    lu = sp.Matrix([l]).jacobian(us)
+    lfx = sp.Matrix([lf]).jacobian(xs)
+    ins = [("p", ps), ("x", xs), ("u", us)]
+    out = HEADER.format(what=f"User-defined plant '{name}' (the Model interface of control/models/model.py:9-43).")
+    out = out.replace("GENERATED by tools/gen_models.py", "GENERATED by ilqr_amd/codegen.py")
+    out += f"#define USER_NX {nx}\n#define USER_NU {nu}\n#define USER_NP {max(1, n_par)}\n\n"
+    parts = [
+        ("user_gen_dynamics", ins, [("xn", f)], "x_next = discrete_dynamics(x, u)"),
+        ("user_gen_cost_stage", ins, [("c", [l])], "stage cost"),
+        ("user_gen_cost_final", ins[:2], [("c", [lf])], "final cost"),
+        ("user_gen_stage", ins, [("l_x", lx), ("l_u", lu), ("l_xx", lx.jacobian(xs)), ("l_ux", lu.jacobian(xs)),
+                                 ("l_uu", lu.jacobian(us)), ("f_x", f.jacobian(xs)), ("f_u", f.jacobian(us))],
+         "stage derivatives: l_x l_u l_xx l_ux l_uu f_x f_u (row-major)"),
+        ("user_gen_final", ins[:2], [("V_x", lfx), ("V_xx", lfx.jacobian(xs))], "final-cost derivatives"),
+    ]
+    for fname, fins, fouts, doc in parts:
+        text, _ = emit_function(fname, fins, fouts, doc)
+        out += text
+    return out
+
+
+def user_library_dir(key, name, out_root=None):
+    return os.path.join(out_root or os.path.join(_HERE, "lib", "user"), f"{name}_{key}")
+
+
+def build_user_library(nx, nu, n_par, exprs, name, out_root=None, hipcc=None, force=False):
+    """Compile the solver for a traced plant (hipcc, gfx950).  The library lands in
+    <out_root>/<name>_<key>/libilqr_user.so (default out_root: ilqr_amd/lib/user), next to the generated
+    user_gen.h, and is reused when present."""
+    d = user_library_dir(user_key(nx, nu, n_par, exprs), name, out_root)
+    so = os.path.join(d, "libilqr_user.so")
+    if os.path.exists(so) and not force:
+        return so
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "user_gen.h"), "w") as fh:
+        fh.write(generate_user_header(nx, nu, n_par, exprs, name))
+    hipcc = hipcc or os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src = os.path.join(_HERE, "csrc", "ilqr_hip.hip")
+    tmp = so + f".{os.getpid()}.tmp"
+    subprocess.check_call([hipcc, *HIPCC_FLAGS, "-DILQR_USER_MODEL", "-DILQR_ONLY_USER", f"-I{d}", "-o", tmp, src])
+    os.replace(tmp, so)
+    return so

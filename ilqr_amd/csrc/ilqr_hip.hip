@@ -125,10 +125,15 @@ struct ModelDims {
 bool model_dims(int id, ModelDims& d)
 {
     switch (id) {
+#ifdef ILQR_USER_MODEL
+    case ILQR_MODEL_USER: d = {UserModel::NX, UserModel::NU, UserModel::NDX, UserModel::NPAR}; return true;
+#endif
+#ifndef ILQR_ONLY_USER
     case ILQR_MODEL_CAR: d = {CarModel::NX, CarModel::NU, CarModel::NDX, CarModel::NPAR}; return true;
     case ILQR_MODEL_ACROBOT: d = {AcrobotModel::NX, AcrobotModel::NU, AcrobotModel::NDX, AcrobotModel::NPAR}; return true;
     case ILQR_MODEL_QUAD_EA: d = {QuadEAModel::NX, QuadEAModel::NU, QuadEAModel::NDX, QuadEAModel::NPAR}; return true;
     case ILQR_MODEL_QUAD_QUAT: d = {QuadQuatModel::NX, QuadQuatModel::NU, QuadQuatModel::NDX, QuadQuatModel::NPAR}; return true;
+#endif
     }
     return false;
 }
@@ -460,12 +465,17 @@ template <class F>
 int dispatch(int model_id, F&& f)
 {
     switch (model_id) {
+#ifdef ILQR_USER_MODEL
+    case ILQR_MODEL_USER: return f(UserModel{});
+#endif
+#ifndef ILQR_ONLY_USER
     case ILQR_MODEL_CAR: return f(CarModel{});
     case ILQR_MODEL_ACROBOT: return f(AcrobotModel{});
     case ILQR_MODEL_QUAD_EA: return f(QuadEAModel{});
     case ILQR_MODEL_QUAD_QUAT: return f(QuadQuatModel{});
+#endif
     }
-    return fail(ILQR_E_BADARG, "unknown model_id");
+    return fail(ILQR_E_BADARG, "model_id not built into this library");
 }
 
 }  // namespace

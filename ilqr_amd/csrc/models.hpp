@@ -19,6 +19,9 @@
 #include "gen/car_gen.h"
 #include "gen/quad_ea_gen.h"
 #include "gen/quad_quat_gen.h"
+#ifdef ILQR_USER_MODEL
+#include "user_gen.h"   // written by ilqr_amd/codegen.py for a plant the user defined; found through -I
+#endif
 
 namespace ilqr {
 
@@ -74,6 +77,51 @@ struct CarModel {
         diff_sub<NX>(s, r, dx);
     }
 };
+
+#ifdef ILQR_USER_MODEL
+// ------------------------------------------- plant defined by the user
+// The reference's own extension point (README.md:25-31): the user writes
+// discrete_dynamics, _cost_stage and _cost_final; derivatives are taken
+// symbolically (car.py:30-52).  Here those three functions were traced once and
+// printed as user_gen_* with the car's signatures; par holds USER_NP numbers
+// the user may change between solves without rebuilding.
+struct UserModel {
+    static constexpr int NX = USER_NX, NU = USER_NU, NDX = USER_NX, NPAR = USER_NP;
+    static constexpr bool UNROLL = true;
+    static constexpr bool TEAM_BACKWARD = false;
+    static constexpr int BACKWARD_WAVES = 1;
+    static_assert(NX + NU <= 8, "the lane-per-trajectory backward stage keeps every matrix in registers");
+    __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
+    {
+        user_gen_dynamics(par, x, u, xn);
+    }
+    __device__ static double cost_stage(const double* par, const double* x, const double* u)
+    {
+        double c;
+        user_gen_cost_stage(par, x, u, &c);
+        return c;
+    }
+    __device__ static double cost_final(const double* par, const double* x)
+    {
+        double c;
+        user_gen_cost_final(par, x, &c);
+        return c;
+    }
+    __device__ static void stage(const double* par, const double* x, const double* u, double* lx, double* lu,
+                                 double* lxx, double* lux, double* luu, double* fx, double* fu)
+    {
+        user_gen_stage(par, x, u, lx, lu, lxx, lux, luu, fx, fu);
+    }
+    __device__ static void final(const double* par, const double* x, double* Vx, double* Vxx)
+    {
+        user_gen_final(par, x, Vx, Vxx);
+    }
+    __device__ static void diff_state(const double*, const double* s, const double* r, double* dx)
+    {
+        diff_sub<NX>(s, r, dx);
+    }
+};
+#endif
 
 // ------------------------------------------------- RK4 (acrobot.py:76-97)
 template <int NX, void (*XDOT)(const double*, const double*, double*)>

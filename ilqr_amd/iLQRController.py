@@ -51,8 +51,9 @@ class iLQR:
         self._solver_key = None
         if getattr(model, "_model_id", None) is None:
             raise TypeError(
-                f"{type(model).__name__} has no generated device code: only CarModel, Acrobot2DModel, "
-                "QuadrotorEAModel and QuadrotorQuatModel from ilqr_amd.models can be solved on the GPU")
+                f"{type(model).__name__} has no generated device code: use CarModel, Acrobot2DModel, "
+                "QuadrotorEAModel or QuadrotorQuatModel from ilqr_amd.models, or define the plant through "
+                "ilqr_amd.models.user.UserModel")
         mN = getattr(model, "N", None)
         if mN is not None and int(mN) != int(N):
             # the plants' cost_trj sums over the MODEL's N (acrobot.py:139); the kernels use one horizon
@@ -64,7 +65,8 @@ class iLQR:
         key = (par.tobytes(), self.N, self.max_iter, self.max_linesearch_iters, float(self.d_tol), self.trace_len)
         if self._solver is None or key != self._solver_key:
             self._solver = BatchSolver(self.model._model_id, par, self.N, self.max_iter, self.max_linesearch_iters,
-                                       self.d_tol, device=self.device, trace_len=self.trace_len)
+                                       self.d_tol, device=self.device, trace_len=self.trace_len,
+                                       library=getattr(self.model, "_library", None))
             self._solver_key = key
         return self._solver
 

@@ -5,9 +5,13 @@ return shapes).  The arithmetic of every method runs on the GPU through the C
 ABI (`ilqr_model_eval`, `ilqr_rollout_cost`); a model is identified to the
 library by `_model_id` and its parameter block `_param_block()`.
 
-Only the four plants that ship as generated device code can be solved; a
-subclass that overrides the Python-level dynamics or cost is not traced into
-device code and is rejected by `iLQR` with a TypeError.
+The four shipped plants use the generated device code inside libilqr_hip.so.
+A plant written by the user (the reference's README.md:25-31 workflow: subclass
+Model, write discrete_dynamics / _cost_stage / _cost_final) is supported through
+`ilqr_amd.models.user.UserModel`, which traces those three functions into device
+code and carries the path of its own solver library in `_library`.  A subclass
+that merely overrides Python methods of a built-in plant is not traced and is
+rejected by `iLQR` with a TypeError.
 """
 from __future__ import annotations
 
@@ -37,7 +41,7 @@ class Model:
         cache = self.__dict__.setdefault("_eval_cache", {})
         if key not in cache:
             cache.clear()
-            cache[key] = BatchSolver(self._model_id, par, int(N), 1, 1, 0.0)
+            cache[key] = BatchSolver(self._model_id, par, int(N), 1, 1, 0.0, library=getattr(self, "_library", None))
         return cache[key]
 
     def _eval(self, x, u, what):

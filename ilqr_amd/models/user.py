@@ -1,0 +1,130 @@
+"""Plants defined by the user: the reference's extension point, compiled for the GPU.
+
+The reference lets a user solve their own problem by subclassing `Model` and
+writing `discrete_dynamics`, `_cost_stage` and `_cost_final`, with derivatives
+taken symbolically (README.md:25-31, control/models/car.py:12-52, :61-102).
+`UserModel` keeps that workflow:
+
+    from ilqr_amd import sym as m
+    from ilqr_amd.models.user import UserModel
+
+    class Unicycle(UserModel):
+        def __init__(self, goal):
+            super().__init__(nx=3, nu=2, params=goal)      # self.p: numbers that may change between solves
+        def discrete_dynamics(self, x, u):
+            return m.array([x[0] + 0.1 * u[0] * m.cos(x[2]), x[1] + 0.1 * u[0] * m.sin(x[2]), x[2] + 0.1 * u[1]])
+        def _cost_stage(self, x, u):
+            return (x[0] - self.p[0]) ** 2 + (x[1] - self.p[1]) ** 2 + 0.1 * (u[0] ** 2 + u[1] ** 2)
+        def _cost_final(self, x):
+            return 100 * ((x[0] - self.p[0]) ** 2 + (x[1] - self.p[1]) ** 2)
+
+    plant = Unicycle([2.0, 1.0]); plant.build()            # hipcc, once per distinct plant; reused afterwards
+    x, u = iLQR(plant, N=50, max_iter=50).run_ilqr(x0, u0)
+
+`build()` runs the three methods once on SymPy symbols (x, u and `self.p`
+become symbols), differentiates, prints straight-line C and compiles the whole
+solver for that plant into its own shared library under ilqr_amd/lib/user/.
+After `build()` the Model interface (discrete_dynamics, stage, final, rollout,
+cost_trj, ...) evaluates on the GPU like the shipped plants; the Python methods
+the user wrote stay reachable as `python_dynamics`, `python_cost_stage`,
+`python_cost_final`.  State plus control dimension is limited to 8 (the
+lane-per-trajectory backward stage keeps every matrix in registers).
+"""
+from __future__ import annotations
+
+import os
+import types
+
+import numpy as np
+
+from .. import _lib
+from .model import Model
+
+
+class UserModel(Model):
+    _model_id = _lib.MODEL_USER
+
+    def __init__(self, nx: int, nu: int, params=None, name: str | None = None):
+        super().__init__()
+        self.nx, self.nu, self.ndx = int(nx), int(nu), int(nx)
+        self.p = np.array([] if params is None else params, dtype=np.float64).ravel()
+        self.name = name or type(self).__name__.lower()
+        self._library = None
+        cls = type(self)
+        for meth in ("discrete_dynamics", "_cost_stage", "_cost_final"):
+            if getattr(cls, meth) is getattr(Model, meth):
+                raise TypeError(f"{cls.__name__} must define {meth} (README.md:25-31 of the reference)")
+        self._user = (cls.discrete_dynamics, cls._cost_stage, cls._cost_final)
+
+    # ------------------------------------------------------------ the user's own Python
+    def python_dynamics(self, x, u):
+        return np.asarray(self._user[0](self, np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64)),
+                          dtype=np.float64)
+
+    def python_cost_stage(self, x, u):
+        return float(self._user[1](self, np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64)))
+
+    def python_cost_final(self, x):
+        return float(self._user[2](self, np.asarray(x, dtype=np.float64)))
+
+    # ------------------------------------------------------------ tracing and building
+    def _traced(self, which):
+        fn = self._user[which]
+
+        def call(*args):
+            *xs, p = args
+            saved = self.p
+            self.p = p
+            try:
+                return fn(self, *xs)
+            finally:
+                self.p = saved
+        return call
+
+    def trace(self):
+        """(xs, us, ps, f, l, lf): the three methods run once on SymPy symbols."""
+        from .. import codegen
+        return codegen.user_expressions(self.nx, self.nu, self.p.size, self._traced(0), self._traced(1),
+                                        self._traced(2))
+
+    def header_text(self) -> str:
+        from .. import codegen
+        return codegen.generate_user_header(self.nx, self.nu, self.p.size, self.trace(), self.name)
+
+    def library_dir(self, out_root=None) -> str:
+        """Directory that holds (or will hold) libilqr_user.so and user_gen.h of this plant."""
+        from .. import codegen
+        return codegen.user_library_dir(codegen.user_key(self.nx, self.nu, self.p.size, self.trace()), self.name,
+                                        out_root)
+
+    def build(self, out_root=None, force=False):
+        """Generate and compile (or find already compiled) the solver library for this plant and bind to it."""
+        from .. import codegen
+        self._library = codegen.build_user_library(self.nx, self.nu, self.p.size, self.trace(), self.name, out_root,
+                                                   force=force)
+        self._bind()
+        return self
+
+    def use_library(self, path: str):
+        """Bind to a library built earlier for this same plant (build() on another machine, shipped with an app)."""
+        if not os.path.exists(path):
+            raise _lib.LibraryMissing(f"{path} not found: call build() where hipcc is available")
+        self._library = path
+        self._bind()
+        return self
+
+    def _bind(self):
+        # from here on the Model interface evaluates the compiled code
+        for meth in ("discrete_dynamics", "_cost_stage", "_cost_final"):
+            setattr(self, meth, types.MethodType(getattr(Model, meth), self))
+
+    def _param_block(self):
+        if self._library is None:
+            raise RuntimeError(f"{type(self).__name__}: call build() (or use_library()) before solving")
+        return self.p if self.p.size else np.zeros(1)
+
+    def set_params(self, params):
+        p = np.asarray(params, dtype=np.float64).ravel()
+        if p.size != self.p.size:
+            raise ValueError(f"{type(self).__name__} was traced with {self.p.size} parameters, got {p.size}")
+        self.p = p

@@ -29,7 +29,11 @@ extern "C" {
  *   QUAD_QUAT  [dt, qdiag(12), qfdiag(12), rdiag(4), xref(13), uref(4)]  control/models/Quadrotor_Quat.py:39-59,178-180
  *              (diagonal weights only)
  * matrices are row-major. */
-enum { ILQR_MODEL_CAR = 0, ILQR_MODEL_ACROBOT = 1, ILQR_MODEL_QUAD_EA = 2, ILQR_MODEL_QUAD_QUAT = 3 };
+enum { ILQR_MODEL_CAR = 0, ILQR_MODEL_ACROBOT = 1, ILQR_MODEL_QUAD_EA = 2, ILQR_MODEL_QUAD_QUAT = 3,
+       /* a plant the user wrote (the README.md:25-31 workflow of the reference): present only in a library that
+        * was compiled for that plant (ilqr_amd/codegen.py build_user_library); such a library holds this id alone,
+        * ilqr_model_info reports its dimensions, and params holds the numbers the user declared as changeable */
+       ILQR_MODEL_USER = 4 };
 
 /* why a solve returned: the three ways out of the loop in
  * control/iLQRController.py:43-51, and the numpy.linalg.LinAlgError that

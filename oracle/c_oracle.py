@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libilqr_oracle.so")
 
 TRACE_MAX = 64
-MODEL_IDS = dict(car=0, acrobot=1, quad_ea=2, quad_quat=3)
+MODEL_IDS = dict(car=0, acrobot=1, quad_ea=2, quad_quat=3, user=4)
 EXIT_NAMES = {0: "d_tol", 1: "deltaJ<1", 2: "max_iter", 3: "linalg_error"}
 
 INFO_DTYPE = np.dtype([
@@ -32,15 +32,30 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+def build_user(header_dir: str, out_dir: str = None) -> str:
+    """The checker compiled with the user-defined plant whose user_gen.h lies in header_dir (model id 4)."""
+    out_dir = out_dir or os.path.join(_HERE, "_build", "user_" + os.path.basename(os.path.normpath(header_dir)))
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libilqr_oracle_user.so")
+    src = os.path.join(_HERE, "ilqr_oracle.c")
+    hdr = os.path.join(header_dir, "user_gen.h")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-fopenmp",
+                               "-Wno-unused-function", "-DORACLE_USER_MODEL", f"-I{header_dir}", f"-I{_HERE}",
+                               "-shared", "-o", out, src, "-lm"])
+    return out
+
+
+def lib(path=None):
+    if path is None:
+        path = _LIB_PATH
+        if not os.path.exists(path):
             build()
-        L = C.CDLL(_LIB_PATH)
+    if path not in _libs:
+        L = C.CDLL(path)
         dp = C.POINTER(C.c_double)
         L.ilqr_oracle_solve_batch.restype = C.c_int
         L.ilqr_oracle_solve_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_long,
@@ -55,18 +70,18 @@ def lib():
         L.ilqr_oracle_unit_qterms.argtypes = [C.c_int, C.c_int] + [dp] * 14
         L.ilqr_oracle_unit_gains_vterms.restype = C.c_int
         L.ilqr_oracle_unit_gains_vterms.argtypes = [C.c_int, C.c_int] + [dp] * 10
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return _libs[path]
 
 
 def _p(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def dims(model):
+def dims(model, library=None):
     mid = MODEL_IDS[model] if isinstance(model, str) else model
     v = [C.c_int() for _ in range(4)]
-    lib().ilqr_oracle_model_dims(mid, *[C.byref(x) for x in v])
+    lib(library).ilqr_oracle_model_dims(mid, *[C.byref(x) for x in v])
     return tuple(x.value for x in v)
 
 
@@ -74,10 +89,10 @@ def info_size():
     return INFO_DTYPE.itemsize
 
 
-def solve_batch(model, par, N, max_iter, max_ls, d_tol, x0, u, nthreads=0):
+def solve_batch(model, par, N, max_iter, max_ls, d_tol, x0, u, nthreads=0, library=None):
     """x0[B,nx], u[B,N-1,nu] (not modified) -> dict(x[B,N,nx], u[B,N-1,nu], info structured array)."""
     mid = MODEL_IDS[model] if isinstance(model, str) else model
-    nx, nu, ndx, npar = dims(mid)
+    nx, nu, ndx, npar = dims(mid, library)
     par = np.ascontiguousarray(par, dtype=np.float64)
     assert par.size == npar, (par.size, npar)
     x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, nx)
@@ -87,22 +102,22 @@ def solve_batch(model, par, N, max_iter, max_ls, d_tol, x0, u, nthreads=0):
     info = np.zeros(B, dtype=INFO_DTYPE)
     if nthreads <= 0:
         nthreads = len(os.sched_getaffinity(0))
-    rc = lib().ilqr_oracle_solve_batch(mid, _p(par), N, max_iter, max_ls, float(d_tol), B, _p(x0), _p(u), _p(x),
+    rc = lib(library).ilqr_oracle_solve_batch(mid, _p(par), N, max_iter, max_ls, float(d_tol), B, _p(x0), _p(u), _p(x),
                                        info.ctypes.data_as(C.c_void_p), nthreads)
     assert rc == 0
     return dict(x=x, u=u, info=info)
 
 
-def eval_point(model, par, x, u):
+def eval_point(model, par, x, u, library=None):
     mid = MODEL_IDS[model] if isinstance(model, str) else model
-    nx, nu, ndx, npar = dims(mid)
+    nx, nu, ndx, npar = dims(mid, library)
     par = np.ascontiguousarray(par, dtype=np.float64)
     x = np.ascontiguousarray(x, dtype=np.float64)
     u = np.ascontiguousarray(u, dtype=np.float64)
     out = dict(xn=np.zeros(nx), cs=np.zeros(1), cf=np.zeros(1), l_x=np.zeros(nx), l_u=np.zeros(nu),
                l_xx=np.zeros((nx, nx)), l_ux=np.zeros((nu, nx)), l_uu=np.zeros((nu, nu)),
                f_x=np.zeros((ndx, ndx)), f_u=np.zeros((ndx, nu)), V_x=np.zeros(ndx), V_xx=np.zeros((ndx, ndx)))
-    rc = lib().ilqr_oracle_eval(mid, _p(par), _p(x), _p(u), *[_p(out[k]) for k in
+    rc = lib(library).ilqr_oracle_eval(mid, _p(par), _p(x), _p(u), *[_p(out[k]) for k in
                                 ("xn", "cs", "cf", "l_x", "l_u", "l_xx", "l_ux", "l_uu", "f_x", "f_u", "V_x", "V_xx")])
     assert rc == 0
     out["cs"] = float(out["cs"][0]); out["cf"] = float(out["cf"][0])

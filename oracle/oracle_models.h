@@ -391,8 +391,37 @@ static void q_terms_quat(const ilqr_oracle_model *M, const double *par, const do
     q_terms_default_export(M, par, x, plx, lu, plxx, plux, luu, fx, fu, Vx, Vxx, Qx, Qu, Qxx, Qux, Quu);
 }
 
+#ifdef ORACLE_USER_MODEL
+/* A plant the user wrote (README.md:25-31 of the reference; derivatives taken symbolically as in
+ * control/models/car.py:30-52).  user_gen.h is the traced, printed form of the user's three functions. */
+#include "user_gen.h"
+static void user_dynamics(const double *par, const double *x, const double *u, double *xn)
+{
+    user_gen_dynamics(par, x, u, xn);
+}
+static double user_cost_stage(const double *par, const double *x, const double *u)
+{
+    double c;
+    user_gen_cost_stage(par, x, u, &c);
+    return c;
+}
+static double user_cost_final(const double *par, const double *x)
+{
+    double c;
+    user_gen_cost_final(par, x, &c);
+    return c;
+}
+DEF_DIFF_SUB(user_diff, USER_NX)
+#endif
+
 static const ilqr_oracle_model *oracle_model_table(int id)
 {
+#ifdef ORACLE_USER_MODEL
+    static const ilqr_oracle_model U = {USER_NX, USER_NU, USER_NX, USER_NP, user_dynamics, user_cost_stage,
+                                        user_cost_final, user_gen_stage, user_gen_final, user_diff,
+                                        q_terms_default_export};
+    if (id == 4) return &U;
+#endif
     static const ilqr_oracle_model T[4] = {
         {5, 2, 5, 2, car_dynamics, car_cost_stage, car_cost_final, car_stage_derivs, car_final_derivs, car_diff,
          q_terms_default_export},

@@ -75,10 +75,11 @@ def test_argument_validation_and_workspace(L):
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from ilqr_amd import _lib
-    monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.LibraryMissing):
         _lib.lib()
+    with pytest.raises(_lib.LibraryMissing):
+        _lib.lib(str(tmp_path / "user" / "libilqr_user.so"))
 
 
 def test_no_cpu_device_path():

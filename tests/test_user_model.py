@@ -1,0 +1,189 @@
+"""A plant defined by the user (the reference's README.md:25-31 workflow): traced, printed as C, compiled.
+
+CPU tests: the printed C against the user's own Python and against SymPy's evaluation of the derivatives;
+the CPU checker compiled with that plant against a golden produced by the reference's iLQR class running the
+same Python plant (tools/make_golden.py, tests/golden/user_rover.npz).
+GPU tests: the solver library compiled for the plant (built beforehand by __graft_entry__.build()) against that
+golden and against the checker.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from helpers import compare_to_golden, rel_traj
+from user_models import ROVER_SP, Rover, rover_inputs
+
+
+@pytest.fixture(scope="module")
+def rover_checker(oracle, tmp_path_factory):
+    """Path of the CPU checker compiled with the Rover plant."""
+    d = tmp_path_factory.mktemp("rover_hdr")
+    (d / "user_gen.h").write_text(Rover().header_text())
+    return oracle.build_user(str(d), out_dir=str(d))
+
+
+def test_printed_c_matches_the_users_python(oracle, rover_checker):
+    import sympy as sp
+    plant = Rover()
+    xs, us, ps, f, l, lf = plant.trace()
+    lx = sp.Matrix([l]).jacobian(xs); lu = sp.Matrix([l]).jacobian(us); lfx = sp.Matrix([lf]).jacobian(xs)
+    ex = dict(l_x=lx, l_u=lu, l_xx=lx.jacobian(xs), l_ux=lu.jacobian(xs), l_uu=lu.jacobian(us), f_x=f.jacobian(xs),
+              f_u=f.jacobian(us), V_x=lfx, V_xx=lfx.jacobian(xs))
+    fn = {k: sp.lambdify([*xs, *us, *ps], v, "numpy") for k, v in ex.items()}
+    rng = np.random.default_rng(5)
+    assert oracle.dims("user", rover_checker) == (4, 2, 4, 4)
+    for _ in range(50):
+        x = rng.uniform(-2, 2, 4); u = rng.standard_normal(2)
+        plant.set_params(rng.uniform(-3, 3, 4))
+        e = oracle.eval_point("user", plant.p, x, u, library=rover_checker)
+        assert np.allclose(e["xn"], plant.python_dynamics(x, u), rtol=1e-14, atol=1e-15)
+        assert np.isclose(e["cs"], plant.python_cost_stage(x, u), rtol=1e-13)
+        assert np.isclose(e["cf"], plant.python_cost_final(x), rtol=1e-13)
+        for k in fn:
+            want = np.asarray(fn[k](*x, *u, *plant.p), dtype=np.float64).reshape(e[k].shape)
+            assert np.allclose(e[k], want, rtol=1e-12, atol=1e-13), k
+
+
+def test_checker_with_user_plant_matches_reference_golden(oracle, rover_checker):
+    g = load_golden("user_rover")
+    r = oracle.solve_batch("user", g["par"], int(g["N"]), int(g["max_iter"]), int(g["max_ls"]), float(g["d_tol"]),
+                           g["x0"], g["u_init"], library=rover_checker)
+    i = r["info"]
+    n = compare_to_golden(g, r["x"], r["u"], i["J_last"], i["iters"], i["status"], i["ls_evals"], i["accepted"],
+                          i["regu_rounds"], J0=i["J0"], label="user_rover")
+    assert n >= 40
+    assert (g["regu_rounds"] > 0).all() and (g["ls_evals"] > 1).any()     # the fixture exercises both loops
+
+
+def test_library_key_is_stable_across_processes():
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); from user_models import Rover; "
+            "print(Rover().library_dir())" % (ROOT, os.path.join(ROOT, "tests")))
+    outs = set()
+    for seed in ("0", "12345"):
+        env = dict(os.environ, PYTHONHASHSEED=seed)
+        outs.add(subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip())
+    outs.add(Rover().library_dir())
+    assert len(outs) == 1, outs
+    assert Rover(goal=(0.0, 0.0)).library_dir() in outs          # parameters are not part of the plant's identity
+
+
+def test_user_model_contract():
+    from ilqr_amd import sym as m
+    from ilqr_amd.iLQRController import iLQR
+    from ilqr_amd.models.user import UserModel
+
+    class NoCost(UserModel):
+        def discrete_dynamics(self, x, u):
+            return x
+
+    with pytest.raises(TypeError, match="_cost_stage"):
+        NoCost(2, 1)
+
+    class Wide(UserModel):
+        def discrete_dynamics(self, x, u):
+            return x
+
+        def _cost_stage(self, x, u):
+            return x[0] ** 2
+
+        def _cost_final(self, x):
+            return x[0] ** 2
+
+    with pytest.raises(NotImplementedError, match="nx \\+ nu"):
+        Wide(7, 2).trace()
+    assert len(Wide(3, 1).trace()[3]) == 3
+
+    class WrongLen(Wide):
+        def discrete_dynamics(self, x, u):
+            return m.array([x[0], x[1]])
+
+    with pytest.raises(ValueError, match="expected nx"):
+        WrongLen(3, 1).trace()
+    with pytest.raises(RuntimeError, match="build"):
+        iLQR(Rover(), **dict(N=10, max_iter=1))._get_solver()
+    with pytest.raises(ValueError, match="traced with 4"):
+        Rover().set_params([1.0])
+
+
+# ----------------------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def rover_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    plant = Rover()
+    # built in-tree beforehand (__graft_entry__.build()); never compiled inside a GPU test
+    return plant.use_library(os.path.join(plant.library_dir(), "libilqr_user.so"))
+
+
+@pytest.fixture(scope="module")
+def rover_checker_gpu(oracle, rover_gpu):
+    return oracle.build_user(rover_gpu.library_dir())
+
+
+def _solve(plant, sp, x0, u0):
+    from ilqr_amd.iLQRController import iLQR
+    ctl = iLQR(plant, sp["N"], sp["max_iter"], sp["max_ls"], sp["d_tol"], trace_len=64)
+    u = np.array(u0, copy=True)
+    x, u = ctl.run_ilqr(np.array(x0), u)
+    return ctl.info, x, u
+
+
+@pytest.mark.gpu
+def test_user_plant_on_gpu_matches_reference_golden(rover_gpu):
+    g = load_golden("user_rover")
+    rover_gpu.set_params(g["par"])
+    sp = dict(N=int(g["N"]), max_iter=int(g["max_iter"]), max_ls=int(g["max_ls"]), d_tol=float(g["d_tol"]))
+    info, x, u = _solve(rover_gpu, sp, g["x0"], g["u_init"])
+    t = info.traces
+    n = compare_to_golden(g, x, u, info.J.cpu().numpy(), info.iters.cpu().numpy(), info.status.cpu().numpy(),
+                          t["ls_evals"].cpu().numpy(), t["accepted"].cpu().numpy(), info.regu_rounds.cpu().numpy(),
+                          J0=info.J0.cpu().numpy(), label="user_rover")
+    assert n >= 40
+
+
+@pytest.mark.gpu
+def test_user_plant_on_gpu_matches_checker_with_changed_parameters(oracle, rover_gpu, rover_checker_gpu):
+    """New goal and obstacle without rebuilding; a seeded batch against the checker compiled with the same plant."""
+    par = np.array([-2.0, 2.5, -0.8, 1.1])
+    rover_gpu.set_params(par)
+    x0, u0 = rover_inputs(512, 99)
+    info, x, u = _solve(rover_gpu, ROVER_SP, x0, u0)
+    r = oracle.solve_batch("user", par, ROVER_SP["N"], ROVER_SP["max_iter"], ROVER_SP["max_ls"], ROVER_SP["d_tol"],
+                           x0, u0, library=rover_checker_gpu)
+    i = r["info"]
+    same = ((info.iters.cpu().numpy() == i["iters"]) & (info.status.cpu().numpy() == i["status"])
+            & (info.regu_rounds.cpu().numpy() == i["regu_rounds"]) & (info.ls_total.cpu().numpy() == i["ls_total"]))
+    assert same.mean() >= 0.9, same.mean()       # the rest: solves that amplify rounding differences (ill-conditioned)
+    rx = rel_traj(x[same], r["x"][same]); ru = rel_traj(u[same], r["u"][same])
+    tight = (rx <= 1e-8) & (ru <= 1e-8)
+    assert tight.mean() >= 0.9, (tight.mean(), np.sort(rx)[-5:])
+    Jg, Jc = info.J.cpu().numpy()[same][tight], i["J_last"][same][tight]
+    assert np.allclose(Jg, Jc, rtol=1e-8, atol=0, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_user_plant_model_interface_on_gpu(oracle, rover_gpu, rover_checker_gpu):
+    rng = np.random.default_rng(3)
+    rover_gpu.set_params([3.0, 1.0, 1.5, 0.4])
+    for _ in range(5):
+        x = rng.uniform(-2, 2, 4); u = rng.standard_normal(2)
+        e = oracle.eval_point("user", rover_gpu.p, x, u, library=rover_checker_gpu)
+        assert np.allclose(rover_gpu.discrete_dynamics(x, u), e["xn"], rtol=1e-13, atol=1e-14)
+        assert np.allclose(rover_gpu.discrete_dynamics(x, u), rover_gpu.python_dynamics(x, u), rtol=1e-13, atol=1e-14)
+        assert np.isclose(rover_gpu._cost_stage(x, u), rover_gpu.python_cost_stage(x, u), rtol=1e-12)
+        assert np.isclose(rover_gpu._cost_final(x), rover_gpu.python_cost_final(x), rtol=1e-12)
+        for got, k in zip(rover_gpu.stage(x, u), ("l_x", "l_u", "l_xx", "l_ux", "l_uu", "f_x", "f_u")):
+            assert np.allclose(got.reshape(e[k].shape), e[k], rtol=1e-12, atol=1e-13), k
+        for got, k in zip(rover_gpu.final(x), ("V_x", "V_xx")):
+            assert np.allclose(got.reshape(e[k].shape), e[k], rtol=1e-12, atol=1e-13), k
+    # a built-in plant is not in this library, and the built-in library does not hold the user's plant
+    from ilqr_amd import _lib
+    with pytest.raises(RuntimeError, match="unknown model_id"):
+        _lib.model_info(_lib.MODEL_CAR, _lib.lib(rover_gpu._library))
+    with pytest.raises(RuntimeError, match="unknown model_id"):
+        _lib.model_info(_lib.MODEL_USER)

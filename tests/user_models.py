@@ -1,0 +1,47 @@
+"""A plant written the way a user of the solver would write one (used by the user-model tests and goldens)."""
+import numpy as np
+
+from ilqr_amd import sym as m
+from ilqr_amd.models.user import UserModel
+
+
+class Rover(UserModel):
+    """Unicycle with a speed state driving to a goal past a soft circular obstacle.
+
+    x = [px, py, heading, speed], u = [acceleration, turn rate], p = [goal_x, goal_y, obstacle_x, obstacle_y].
+    The obstacle bump has negative curvature, so the backward pass has to regularise (iLQRController.py:110-113).
+    """
+    DT = 0.1
+
+    def __init__(self, goal=(3.0, 1.0), obstacle=(1.5, 0.4)):
+        super().__init__(nx=4, nu=2, params=[*goal, *obstacle], name="rover")
+
+    def discrete_dynamics(self, x, u):
+        h = self.DT
+        return m.array([x[0] + h * x[3] * m.cos(x[2]),
+                        x[1] + h * x[3] * m.sin(x[2]),
+                        x[2] + h * u[1],
+                        x[3] + h * u[0]])
+
+    def _bump(self, x):
+        d2 = (x[0] - self.p[2]) ** 2 + (x[1] - self.p[3]) ** 2
+        return 4.0 * m.exp(-d2 / 0.18)
+
+    def _cost_stage(self, x, u):
+        goal = (x[0] - self.p[0]) ** 2 + (x[1] - self.p[1]) ** 2
+        return 0.05 * goal + self._bump(x) + 0.1 * u[0] ** 2 + 0.05 * u[1] ** 2 + 0.01 * x[3] ** 2
+
+    def _cost_final(self, x):
+        goal = (x[0] - self.p[0]) ** 2 + (x[1] - self.p[1]) ** 2
+        return 50.0 * goal + 5.0 * x[3] ** 2
+
+
+ROVER_SP = dict(N=60, max_iter=60, max_ls=20, d_tol=1e-3)
+
+
+def rover_inputs(B, seed):
+    rng = np.random.default_rng(seed)
+    x0 = np.column_stack([rng.uniform(-1, 1, B), rng.uniform(-1, 1, B), rng.uniform(-np.pi, np.pi, B),
+                          rng.uniform(0, 1.5, B)])
+    u0 = 0.3 * rng.standard_normal((B, ROVER_SP["N"] - 1, 2))
+    return x0, u0

@@ -31,7 +31,6 @@ import sys
 import time
 
 import sympy as sp
-from sympy.printing.c import C99CodePrinter
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -40,162 +39,10 @@ from oracle import models_numpy as mn  # noqa: E402
 OUT_DIRS = [os.path.join(ROOT, "ilqr_amd", "csrc", "gen"), os.path.join(ROOT, "oracle", "gen")]
 
 
-class _Printer(C99CodePrinter):
-    """C printer that never calls pow() for the small rational powers that occur."""
+import ilqr_amd.codegen as _cg  # noqa: E402
+from ilqr_amd.codegen import HEADER, emit_function  # noqa: E402
 
-    def _print_Pow(self, expr):
-        b, e = expr.base, expr.exp
-        if e.is_Integer:
-            n = int(e)
-            bs = self.parenthesize(b, 1000)
-            if n == 0:
-                return "1.0"
-            mul = "*".join([bs] * abs(n))
-            return f"({mul})" if n > 0 else f"(1.0/({mul}))"
-        if e.is_Rational and e.q == 2:
-            n = int(e.p)
-            bs = self._print(b)
-            root = f"sqrt({bs})"
-            k = abs(n)
-            # b^(k/2) = b^(k//2) * sqrt(b) for odd k
-            pw = "*".join([f"({bs})"] * (k // 2) + [root])
-            return f"({pw})" if n > 0 else f"(1.0/({pw}))"
-        return super()._print_Pow(expr)
-
-    def _print_Rational(self, expr):
-        return f"({float(expr.p)!r}/{float(expr.q)!r})"
-
-    def _print_Integer(self, expr):
-        return f"{float(int(expr))!r}"
-
-    def _print_Float(self, expr):
-        return repr(float(expr))
-
-
-_P = _Printer()
-
-
-def _count_ops(exprs):
-    """Count arithmetic in a list of (already CSE'd) expressions.
-    FMA-able mul+add pairs are counted as separate mul and add (2 flops)."""
-    c = dict(add=0, mul=0, div=0, sqrt=0, sin=0, cos=0, tan=0)
-    for e in exprs:
-        for node in sp.preorder_traversal(e):
-            if isinstance(node, sp.Add):
-                c["add"] += len(node.args) - 1
-            elif isinstance(node, sp.Mul):
-                nargs = len(node.args)
-                # a*b**-1 is a division
-                ndiv = sum(1 for a in node.args if isinstance(a, sp.Pow) and a.exp.is_negative)
-                c["mul"] += max(nargs - 1 - ndiv, 0)
-                c["div"] += ndiv
-            elif isinstance(node, sp.Pow):
-                ex = node.exp
-                if ex.is_Integer:
-                    c["mul"] += abs(int(ex)) - 1
-                    # a lone reciprocal (not inside a Mul) is handled by the Mul case mostly
-                elif ex.is_Rational and ex.q == 2:
-                    c["sqrt"] += 1
-                    c["mul"] += abs(int(ex.p)) // 2
-            elif isinstance(node, sp.sin):
-                c["sin"] += 1
-            elif isinstance(node, sp.cos):
-                c["cos"] += 1
-            elif isinstance(node, sp.tan):
-                c["tan"] += 1
-    c["flops"] = sum(c.values())
-    return c
-
-
-def emit_function(name, inputs, outputs, doc, pre=None):
-    """inputs: list of (cname, [symbols]); outputs: list of (cname, sympy Matrix or list).
-    Dense row-major outputs; structural zeros are written as 0.0.
-    pre: optional list of (symbol, expression) evaluated first, in order, as named temporaries."""
-    flat = []
-    for _, M in outputs:
-        M = sp.Matrix(M)
-        flat.extend(list(M))          # row-major
-    pre = pre or []
-    npre = len(pre)
-    flat = [e for _, e in pre] + flat
-    t0 = time.time()
-    # sin(a) and cos(a) of the same argument share one range reduction: both come from one ILQR_SINCOS
-    kinds = {}
-    for e in flat:
-        for node in sp.preorder_traversal(e):
-            if isinstance(node, (sp.sin, sp.cos)):
-                kinds.setdefault(node.args[0], set()).add(type(node))
-    pairs = [a for a, k in kinds.items() if k == {sp.sin, sp.cos} and not a.has(sp.sin, sp.cos, sp.tan)]
-    pairs.sort(key=str)
-    sc = {a: (sp.Symbol(f"sn{i}"), sp.Symbol(f"cs{i}")) for i, a in enumerate(pairs)}
-    if sc:
-        rep = {}
-        for a, (S, Cc) in sc.items():
-            rep[sp.sin(a)] = S
-            rep[sp.cos(a)] = Cc
-        flat = [e.xreplace(rep) for e in flat]
-    repl, red = sp.cse(flat, symbols=sp.numbered_symbols("t"), optimizations="basic", order="none")
-    lines = []
-    args = ", ".join([f"const double* __restrict__ {n}" for n, _ in inputs] +
-                     [f"double* __restrict__ {n}" for n, _ in outputs])
-    lines.append(f"/* {doc} */")
-    lines.append(f"ILQR_HD static inline void {name}({args})")
-    lines.append("{")
-    sub = {}
-    for n, syms in inputs:
-        for i, s in enumerate(syms):
-            sub[s] = sp.Symbol(f"{n}[{i}]")
-    used = set()
-    for e in [r for _, r in repl] + red:
-        used |= e.free_symbols
-    for n, syms in inputs:
-        if not any(s in used for s in syms):
-            lines.append(f"    (void){n};")
-    for a in pairs:
-        S, Cc = sc[a]
-        lines.append(f"    double {S}, {Cc};")
-        lines.append(f"    ILQR_SINCOS({_P.doprint(a.xreplace(sub))}, {S}, {Cc});")
-    for t, e in repl:
-        lines.append(f"    const double {t} = {_P.doprint(e.xreplace(sub))};")
-    for k in range(npre):
-        lines.append(f"    const double {pre[k][0]} = {_P.doprint(red[k].xreplace(sub))};")
-    red = red[npre:]
-    k = 0
-    for n, M in outputs:
-        M = sp.Matrix(M)
-        for i in range(len(M)):
-            lines.append(f"    {n}[{i}] = {_P.doprint(red[k].xreplace(sub))};")
-            k += 1
-    lines.append("}")
-    ops = _count_ops([e for _, e in repl] + red)
-    ops["sin"] += len(pairs); ops["cos"] += len(pairs); ops["flops"] += 2 * len(pairs)
-    sys.stderr.write(f"  {name}: {len(repl)} temporaries, {ops['flops']} flops, cse {time.time() - t0:.1f}s\n")
-    return "\n".join(lines) + "\n", ops
-
-
-HEADER = """/* GENERATED by tools/gen_models.py -- do not edit.
- * {what}
- * Dense row-major outputs.  ILQR_HD = __host__ __device__ under hipcc.
- */
-#pragma once
-#include <math.h>
-#ifndef ILQR_HD
-#  if defined(__HIPCC__)
-#    define ILQR_HD __host__ __device__
-#  else
-#    define ILQR_HD
-#  endif
-#endif
-/* sine and cosine of one argument: one shared range reduction on the GPU */
-#ifndef ILQR_SINCOS
-#  if defined(__HIP_DEVICE_COMPILE__)
-#    define ILQR_SINCOS(a, s, c) sincos((a), &(s), &(c))
-#  else
-#    define ILQR_SINCOS(a, s, c) ((s) = sin(a), (c) = cos(a))
-#  endif
-#endif
-
-"""
+_cg.VERBOSE = True
 
 
 def gen_car():

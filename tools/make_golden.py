@@ -56,7 +56,61 @@ def models():
     return _M
 
 
+_USER_FN = {}
+
+
+def make_user_plant(spec):
+    """A plant written by the user (tests/user_models.py) as a subclass of the imported reference `Model`:
+    its own Python dynamics and costs, derivatives from SymPy lambdify of the same expressions
+    (the car.py:30-52 recipe with SymPy in place of pydrake.symbolic)."""
+    import sympy as sp
+    from control.models.model import Model
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import user_models
+    um = getattr(user_models, spec["cls"])(*spec.get("args", ()))
+    key = (spec["cls"], tuple(um.p))
+    if key not in _USER_FN:
+        xs, us, ps, f, l, lf = um.trace()
+        sub = dict(zip(ps, um.p))
+        f, l, lf = f.subs(sub), l.subs(sub), lf.subs(sub)
+        lx = sp.Matrix([l]).jacobian(xs); lu = sp.Matrix([l]).jacobian(us); lfx = sp.Matrix([lf]).jacobian(xs)
+        ex = dict(l_x=lx, l_u=lu, l_xx=lx.jacobian(xs), l_ux=lu.jacobian(xs), l_uu=lu.jacobian(us),
+                  f_x=f.jacobian(xs), f_u=f.jacobian(us), lf_x=lfx, lf_xx=lfx.jacobian(xs))
+        _USER_FN[key] = {k: sp.lambdify(list(xs) + (list(us) if not k.startswith("lf") else []), v, "numpy")
+                         for k, v in ex.items()}
+    fn = _USER_FN[key]
+    n, m = um.nx, um.nu
+
+    class Plant(Model):
+        def __init__(self):
+            self.nx, self.nu, self.ndx = n, m, n
+            self.p = um.p
+
+        def discrete_dynamics(self, x, u):
+            return um.python_dynamics(x, u)
+
+        def _cost_stage(self, x, u):
+            return um.python_cost_stage(x, u)
+
+        def _cost_final(self, x):
+            return um.python_cost_final(x)
+
+        def stage(self, x, u):
+            a = (*x, *u)
+            g = lambda k, shp: np.asarray(fn[k](*a), dtype=np.float64).reshape(shp)
+            return (g("l_x", n), g("l_u", m), g("l_xx", (n, n)), g("l_ux", (m, n)), g("l_uu", (m, m)),
+                    g("f_x", (n, n)), g("f_u", (n, m)))
+
+        def final(self, x):
+            return (np.asarray(fn["lf_x"](*x), dtype=np.float64).reshape(n),
+                    np.asarray(fn["lf_xx"](*x), dtype=np.float64).reshape(n, n))
+
+    return Plant()
+
+
 def make_plant(spec):
+    if spec["model"] == "user":
+        return make_user_plant(spec)
     M = models()
     kind = spec["model"]
     if kind == "car":
@@ -71,6 +125,8 @@ def make_plant(spec):
 
 def par_block(spec):
     from oracle import c_oracle as co
+    if spec["model"] == "user":
+        return np.asarray(make_user_plant(spec).p, dtype=np.float64)
     if spec["model"] == "car":
         return co.pack_car(spec["r"], spec["v_target"])
     if spec["model"] == "quad_quat":
@@ -394,7 +450,15 @@ def gen_units(pool):
     print("[golden] units", flush=True)
 
 
-GENS = dict(car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
+def gen_user_rover(pool):
+    """A plant defined by the user (tests/user_models.py Rover): random starts around a soft obstacle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from user_models import ROVER_SP, rover_inputs
+    x0, u0 = rover_inputs(48, 2024)
+    run_cases("user_rover", dict(model="user", cls="Rover"), ROVER_SP, x0, u0, pool)
+
+
+GENS = dict(user_rover=gen_user_rover, car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
             acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat, units=gen_units)
 
 
