@@ -189,7 +189,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_export_kernel(Pipe a)
 template <class M>
 __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kernel(Pipe a)
 {
-    __shared__ double lds[stage_lds_doubles<M::NDX, M::NU>()];
+    __shared__ double lds[stage_lds_doubles<M::NDX, M::NU, TermsOf<M>::type::AUX>()];
     const int s0 = blockIdx.x * PIPE_WG + threadIdx.x;
     const bool live = s0 < a.count;
     const int s = live ? s0 : a.count - 1;      // a lane without a trajectory shadows the last one and stores nothing

@@ -292,18 +292,20 @@ template <int w, int UF>
 __device__ inline int has_negative_eig_packed(double* L, double& maxq)
 {
     constexpr int NL = w * (w + 1) / 2;
-    double mq = maxq;
-    double poison = 0.0;    // 0 * entry summed up: stays 0 unless an entry is an infinity or a NaN
-    double acc[w];      // |Q_jj| + sum_k |l_jk^2 d_k|: the size of the terms pivot j is the difference of
+    // largest |entry| and the finite check (0 * entry summed up stays 0 unless an entry is an infinity or a
+    // NaN), each as four independent chains
+    double mqs[4] = {maxq, 0.0, 0.0, 0.0}, poisons[4] = {0.0, 0.0, 0.0, 0.0};
     ILQR_UNROLL
     for (int e = 0; e < NL; ++e) {
-        mq = fmax(mq, fabs(L[e]));          // a NaN entry never wins, as in a chain of `a > mq` comparisons
-        poison = __builtin_fma(0.0, L[e], poison);
+        mqs[e & 3] = fmax(mqs[e & 3], fabs(L[e]));          // a NaN entry never wins, as in a chain of `a > mq` comparisons
+        poisons[e & 3] = __builtin_fma(0.0, L[e], poisons[e & 3]);
     }
+    maxq = fmax(fmax(mqs[0], mqs[1]), fmax(mqs[2], mqs[3]));
+    const double poison = (poisons[0] + poisons[1]) + (poisons[2] + poisons[3]);
+    double acc[w];      // |Q_jj| + sum_k |l_jk^2 d_k|: the size of the terms pivot j is the difference of
     ILQR_UNROLL
     for (int i = 0; i < w; ++i) acc[i] = fabs(L[tri(i, i)]);
-    maxq = mq;
-    // Straight-line code, no early exit: once the verdict is in (`decided`) the remaining steps still run but
+    // Straight-line code, no early exit: once the verdict is in the remaining steps still run but
     // can no longer change it; a skipped (zero) pivot eliminates nothing (pinv = 0).
     bool negative = false;
     ILQR_UNROLL
@@ -312,11 +314,15 @@ __device__ inline int has_negative_eig_packed(double* L, double& maxq)
         const double thr = PIVOT_TOL * acc[j];
         const bool neg = p < -thr;
         const bool zero = !neg && (p <= thr);
+        // a zero pivot over a column that is not zero means indefinite; zero pivots are rare, so the column is
+        // only looked at when some lane of the wavefront has one
         bool nz = false;
-        ILQR_UNROLL
-        for (int i = j + 1; i < w; ++i) {
-            const double c = L[tri(i, j)];
-            nz = nz || (c * c > 4.0 * thr * fabs(L[tri(i, i)]));
+        if (__ballot(zero)) {
+            ILQR_UNROLL
+            for (int i = j + 1; i < w; ++i) {
+                const double c = L[tri(i, j)];
+                nz = nz || (c * c > 4.0 * thr * fabs(L[tri(i, i)]));
+            }
         }
         negative = negative || neg || (zero && nz);
         // the factorisation only decides signs: a reciprocal refined to ~1 ulp is enough, and several times
@@ -361,12 +367,36 @@ constexpr int REGU_GROUPS = 8;    // trajectories per group scan; REGU_GROUPS * 
 // 2^r - 1, the factor of P after r rounds (exact up to r = 53, then 2^r)
 __device__ __forceinline__ double regu_coef(int r) { return ldexp(1.0, r) - 1.0; }
 
-// per-wavefront LDS of the scans, in doubles: Q and P (lower triangles) of up to REGU_GROUPS trajectories
+// Per-wavefront LDS of one backward stage, in doubles:
+//   P of up to REGU_GROUPS published trajectories (lower triangles), the lane numbers of those trajectories,
+//   and per lane the "park": Q(0) (lower triangle) and the plant's aux values, entry e of lane l at
+//   park[e * 64 + l].  Q(0) waits there while the lane factorises its registers in place, the scans read a
+//   published trajectory's Q(0) straight from its lane's park, and a trajectory that needed r rounds
+//   leaves Q(r) there.
 template <int n, int m>
-constexpr int scan_lds_doubles() { return REGU_GROUPS * 2 * QPack<n, m>::NL; }
-// ... followed by what every lane parks there during the PSD tests: Q_x, Q_u and the upper entries of Q
-template <int n, int m>
-constexpr int stage_lds_doubles() { return scan_lds_doubles<n, m>() + 64 * (n + m + QPack<n, m>::NUP); }
+constexpr int scan_lds_doubles() { return REGU_GROUPS * QPack<n, m>::NL + REGU_GROUPS / 2; }
+template <int n, int m, int AUX>
+constexpr int stage_lds_doubles() { return scan_lds_doubles<n, m>() + 64 * (QPack<n, m>::NL + AUX); }
+
+#ifndef ILQR_BUILD_CHUNK
+#define ILQR_BUILD_CHUNK 8
+#endif
+#ifdef ILQR_NO_PHASE_BARRIER
+#define ILQR_PHASE_BARRIER() ((void)0)
+#else
+#define ILQR_PHASE_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+// Q(r) = Q(0) + coef P of a published trajectory, built in registers in portions (all 2 NL LDS reads issued
+// at once would need 2 NL more registers than the factorisation that follows)
+template <int NL>
+__device__ __forceinline__ void build_regularised(double* L, double coef, const double* P, const double* Qpark)
+{
+#pragma unroll
+    for (int e = 0; e < NL; ++e) {
+        L[e] = __builtin_fma(coef, P[e], Qpark[e * 64]);
+        if (e % ILQR_BUILD_CHUNK == ILQR_BUILD_CHUNK - 1) ILQR_PHASE_BARRIER();
+    }
+}
 
 // ------------------------------------------------------------------
 // One stage of the backward Riccati sweep: iLQRController.py:103-122 with
@@ -387,32 +417,34 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
     constexpr int n = M::NDX, m = M::NU, w = n + m;
     constexpr int NL = QP::NL, NUP = QP::NUP;
     constexpr int UF = 64;
-    double Qx[n], Qu[m], QL[NL], QU[NUP > 0 ? NUP : 1], aux[TR::AUX];
-    TR::backward_terms(par, xk, uk, Vx, V, Qx, Qu, QL, QU, aux);
+    double Qx[n], Qu[m], QL[NL], QU[NUP > 0 ? NUP : 1];
+    const int lane = threadIdx.x & 63;
+    double* const ldsP = lds;                                                   // P of the published trajectories
+    int* const srcs = reinterpret_cast<int*>(lds + REGU_GROUPS * NL);           // their lanes
+    double* const park = lds + scan_lds_doubles<n, m>() + lane;                 // this lane's park, stride 64
+    {
+        double aux[TR::AUX];
+        TR::backward_terms(par, xk, uk, Vx, V, Qx, Qu, QL, QU, aux);
+        // The phases of a stage are kept apart for the instruction scheduler: interleaving them saves no time
+        // (each is a long dependent chain of its own) and makes their register needs add up.
+        ILQR_PHASE_BARRIER();
+        ILQR_UNROLL
+        for (int e = 0; e < NL; ++e) park[e * 64] = QL[e];
+        ILQR_UNROLL
+        for (int e = 0; e < TR::AUX; ++e) park[(NL + e) * 64] = aux[e];
+    }
+    ILQR_PHASE_BARRIER();
 
     bool ok = true;
     int r = 0;
-    const int lane = threadIdx.x & 63;
-    double* const ldsP = lds + REGU_GROUPS * NL;                     // P of the published trajectories
-    // What is not needed before the gains (Q_x, Q_u, the upper entries of Q) waits in LDS while the PSD
-    // tests run: the factorisations need every register they can get.  Entry e of lane l at park[e * 64 + l].
-    double* const park = lds + scan_lds_doubles<n, m>();
-    ILQR_UNROLL
-    for (int e = 0; e < n; ++e) park[e * 64 + lane] = Qx[e];
-    ILQR_UNROLL
-    for (int e = 0; e < m; ++e) park[(n + e) * 64 + lane] = Qu[e];
-    ILQR_UNROLL
-    for (int e = 0; e < NUP; ++e) park[(w + e) * 64 + lane] = QU[e];
-    // ---- round-0 test on a copy in every lane, then the wavefront scans
+    // ---- round 0 in every lane, in place (Q(0) itself is in the park), then the wavefront scans
     bool need;
     {
-        double L[NL];
-        ILQR_UNROLL
-        for (int e = 0; e < NL; ++e) L[e] = QL[e];
-        const int neg = has_negative_eig_packed<w, UF>(L, maxq);
+        const int neg = has_negative_eig_packed<w, UF>(QL, maxq);
         ok = ok && (neg >= 0);
         need = alive && (neg == 1);
     }
+    ILQR_PHASE_BARRIER();
     if (need) regu_stages += 1;
     bool stuck_here = false;
 
@@ -426,22 +458,20 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
         const int nsrc = min((int)__popcll(pend), REGU_GROUPS);
         wave_sync();
         if (src) {
-            double PL[NL];
+            double PL[NL], aux[TR::AUX];
+            ILQR_UNROLL
+            for (int e = 0; e < TR::AUX; ++e) aux[e] = park[(NL + e) * 64];
             TR::regu_p(aux, PL);
             ILQR_UNROLL
-            for (int e = 0; e < NL; ++e) {
-                lds[rank * NL + e] = QL[e];
-                ldsP[rank * NL + e] = PL[e];
-            }
+            for (int e = 0; e < NL; ++e) ldsP[rank * NL + e] = PL[e];
+            srcs[rank] = lane;
         }
         wave_sync();
         int t = 1;
         double mq = 0.0;
         if (g < nsrc) {
             double L[NL];
-            const double coef = regu_coef(c + 1);
-            ILQR_UNROLL
-            for (int e = 0; e < NL; ++e) L[e] = __builtin_fma(coef, ldsP[g * NL + e], lds[g * NL + e]);
+            build_regularised<NL>(L, regu_coef(c + 1), ldsP + g * NL, park - lane + srcs[g]);
             t = has_negative_eig_packed<w, UF>(L, mq);
         }
         // first passing round of every group, its verdict, and the largest |Q| met up to it
@@ -456,6 +486,7 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
         const int from = (src ? rank : 0) * REGU_BASE + (cstar >= 0 ? cstar : REGU_BASE - 1);
         const int tt = __shfl(t, from);
         const double mqs = __shfl(mq, from);
+        wave_sync();
         if (src) {
             maxq = fmax(maxq, mqs);
             r = (cstar >= 0) ? cstar + 1 : REGU_BASE;
@@ -463,31 +494,27 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
                 const double coef = regu_coef(r);
                 const double* const pl = ldsP + rank * NL;
                 ILQR_UNROLL
-                for (int e = 0; e < NL; ++e) QL[e] = __builtin_fma(coef, pl[e], QL[e]);
-                // the parked entries above the diagonal get the mirrored entries of P (P is symmetric)
+                for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(coef, pl[e], park[e * 64]);
+                // the entries above the diagonal get the mirrored entries of P (P is symmetric)
                 ILQR_UNROLL
                 for (int i = 0; i < n; ++i)
                     ILQR_UNROLL
-                    for (int j = i + 1; j < n; ++j) {
-                        double* const q = park + (w + upp(n, i, j)) * 64 + lane;
-                        *q = __builtin_fma(coef, pl[tri(j, i)], *q);
-                    }
+                    for (int j = i + 1; j < n; ++j)
+                        QU[upp(n, i, j)] = __builtin_fma(coef, pl[tri(j, i)], QU[upp(n, i, j)]);
                 ILQR_UNROLL
                 for (int i = 0; i < m; ++i)
                     ILQR_UNROLL
-                    for (int j = i + 1; j < m; ++j) {
-                        double* const q = park + (w + upp(m, i, j, QP::UUB)) * 64 + lane;
-                        *q = __builtin_fma(coef, pl[tri(n + j, n + i)], *q);
-                    }
+                    for (int j = i + 1; j < m; ++j)
+                        QU[upp(m, i, j, QP::UUB)] = __builtin_fma(coef, pl[tri(n + j, n + i)], QU[upp(m, i, j, QP::UUB)]);
                 ok = ok && (tt >= 0);
             } else {
-                stuck_here = true;      // Q stays as it came: the stuck scan builds every round from it
+                stuck_here = true;      // Q(0) stays in the park: the stuck scan builds every round from it
             }
             need = false;
         }
         pend &= ~__ballot(src);
     }
-    
+
     // ---- stuck scan: rounds REGU_BASE + 1, + 2, ... of one trajectory, 64 at a time
     unsigned long long stuck = __ballot(stuck_here);
     while (stuck) {
@@ -495,21 +522,17 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
         stuck &= stuck - 1;
         wave_sync();
         if (lane == src) {
-            double PL[NL];
+            double PL[NL], aux[TR::AUX];
+            ILQR_UNROLL
+            for (int e = 0; e < TR::AUX; ++e) aux[e] = park[(NL + e) * 64];
             TR::regu_p(aux, PL);
             ILQR_UNROLL
-            for (int e = 0; e < NL; ++e) {
-                lds[e] = QL[e];
-                ldsP[e] = PL[e];
-            }
+            for (int e = 0; e < NL; ++e) ldsP[e] = PL[e];
         }
-        wave_sync();
         for (int base = REGU_BASE + 1;; base += 64) {
-            const int rc = base + lane;
-            const double coef = regu_coef(rc);
+            wave_sync();     // P and Q(0) are read from LDS again on every trip, not held in registers across the loop
             double L[NL];
-            ILQR_UNROLL
-            for (int e = 0; e < NL; ++e) L[e] = __builtin_fma(coef, ldsP[e], lds[e]);
+            build_regularised<NL>(L, regu_coef(base + lane), ldsP, park - lane + src);
             double mq = 0.0;
             const int t = has_negative_eig_packed<w, UF>(L, mq);
             const unsigned long long stops = __ballot(t != 1);
@@ -517,25 +540,22 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
                 const int win = __ffsll((long long)stops) - 1;
                 const int tw = __shfl(t, win);
                 const double mqw = __shfl(mq, win);
+                wave_sync();
                 if (lane == src) {
                     r = base + win;
                     const double cw = regu_coef(r);
                     ILQR_UNROLL
-                    for (int e = 0; e < NL; ++e) QL[e] = __builtin_fma(cw, ldsP[e], QL[e]);
+                    for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(cw, ldsP[e], park[e * 64]);
                     ILQR_UNROLL
                     for (int i = 0; i < n; ++i)
                         ILQR_UNROLL
-                        for (int j = i + 1; j < n; ++j) {
-                            double* const q = park + (w + upp(n, i, j)) * 64 + lane;
-                            *q = __builtin_fma(cw, ldsP[tri(j, i)], *q);
-                        }
+                        for (int j = i + 1; j < n; ++j)
+                            QU[upp(n, i, j)] = __builtin_fma(cw, ldsP[tri(j, i)], QU[upp(n, i, j)]);
                     ILQR_UNROLL
                     for (int i = 0; i < m; ++i)
                         ILQR_UNROLL
-                        for (int j = i + 1; j < m; ++j) {
-                            double* const q = park + (w + upp(m, i, j, QP::UUB)) * 64 + lane;
-                            *q = __builtin_fma(cw, ldsP[tri(n + j, n + i)], *q);
-                        }
+                        for (int j = i + 1; j < m; ++j)
+                            QU[upp(m, i, j, QP::UUB)] = __builtin_fma(cw, ldsP[tri(n + j, n + i)], QU[upp(m, i, j, QP::UUB)]);
                     ok = ok && (tw >= 0);
                     maxq = fmax(maxq, mqw);
                 }
@@ -548,13 +568,12 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
         }
     }
     regu_rounds += r;
-    if (!ok) return false;
+    // No early return on the LinAlgError cases: the lane goes on with numbers nobody will read (the caller
+    // drops the trajectory).  With a way out in the middle of the stage the old V_x, V_xx would have to stay
+    // in registers through the factorisations for the sake of that path alone.
+    ILQR_PHASE_BARRIER();
     ILQR_UNROLL
-    for (int e = 0; e < n; ++e) Qx[e] = park[e * 64 + lane];
-    ILQR_UNROLL
-    for (int e = 0; e < m; ++e) Qu[e] = park[(n + e) * 64 + lane];
-    ILQR_UNROLL
-    for (int e = 0; e < NUP; ++e) QU[e] = park[(w + e) * 64 + lane];
+    for (int e = 0; e < NL; ++e) QL[e] = park[e * 64];      // Q(r)
 
     // ---- gains (iLQRController.py:125-129): d = -Quu^-1 Qu, K = -Quu^-1 Qux
     double Quu[m * m], Qinv[m * m];
@@ -562,7 +581,7 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
     for (int a = 0; a < m; ++a)
         ILQR_UNROLL
         for (int b = 0; b < m; ++b) Quu[a * m + b] = QP::quu(QL, QU, a, b);
-    if (!inv_small<m>(Quu, Qinv)) return false;
+    ok = inv_small<m>(Quu, Qinv) && ok;
     ILQR_UNROLL
     for (int a = 0; a < m; ++a) {
         double s = 0.0;
@@ -624,7 +643,7 @@ __device__ inline bool backward_stage(const double* par, const double* xk, const
         eb += (0.5 * dk[a]) * s;
     }
     redu += ea - eb;
-    return true;
+    return ok;
 }
 
 // ------------------------------------------------------------------

@@ -279,13 +279,14 @@ static void forward_pass(const ilqr_oracle_model *M, const double *par, const do
 
 /* iLQRController.py:98-123.  Returns 0, or -1 for the LinAlgError cases. */
 /* Diagnostics: histogram of regularisation rounds per stage (index 63 = 63 or more). */
-static long g_regu_hist[64];
+static long g_regu_hist[64 + 128];   /* [0..63]: rounds per stage (63 = more); [64 + r / 16]: coarse bins */
 static int g_regu_hist_on = 0;
+void ilqr_oracle_regu_hist_coarse(long* out128) { memcpy(out128, g_regu_hist + 64, 128 * sizeof(long)); }
 void ilqr_oracle_regu_hist(int enable, long* out64)
 {
-    if (out64) memcpy(out64, g_regu_hist, sizeof(g_regu_hist));
+    if (out64) memcpy(out64, g_regu_hist, 64 * sizeof(long));
     if (enable >= 0) {
-        g_regu_hist_on = enable;
+        g_regu_hist_on = enable & 1;
         memset(g_regu_hist, 0, sizeof(g_regu_hist));
     }
 }
@@ -374,6 +375,9 @@ static int backward_pass(const ilqr_oracle_model *M, const double *par, const do
         }
         if (g_regu_hist_on) {
             long* slot = &g_regu_hist[r < 63 ? r : 63];
+#pragma omp atomic
+            *slot += 1;
+            slot = &g_regu_hist[64 + (r / 16 < 127 ? r / 16 : 127)];
 #pragma omp atomic
             *slot += 1;
         }
