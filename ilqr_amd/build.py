@@ -1,0 +1,56 @@
+"""Build recipe of the solver library (hipcc, gfx950): two translation units, one shared library.
+
+ilqr_hip.hip      the C ABI, host code, rollout / evaluation kernels, the acrobot and the 12-state plants
+lane_plants.hip   the pipeline for the car and for user-defined plants (one trajectory per lane),
+                  compiled with `-mllvm -disable-machine-licm` (csrc/pipeline_host.hpp says why)
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+# -ffp-contract=on: a*b+c fuses only where one source expression says so, so every kernel that inlines a
+# plant function rounds it the same way (costs and rollouts are compared bit for bit between kernels)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC"]
+UNITS = (("ilqr_hip.hip", ()), ("lane_plants.hip", ("-mllvm", "-disable-machine-licm")))
+
+
+def sources():
+    out = [os.path.join(dp, f) for dp, _, fs in os.walk(CSRC) for f in fs if f.endswith((".hip", ".hpp", ".h"))]
+    out.append(os.path.join(os.path.dirname(_HERE), "include", "ilqr_hip.h"))
+    return out
+
+
+def up_to_date(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in deps)
+
+
+def build_library(out_so, defines=(), include_dirs=(), hipcc=None):
+    """Compile both translation units with the given -D / -I options and link them into out_so."""
+    hipcc = hipcc or os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out_dir = os.path.dirname(out_so)
+    os.makedirs(out_dir, exist_ok=True)
+    tag = f"{os.path.basename(out_so)}.{os.getpid()}"
+    objs, procs = [], []
+    common = [*HIPCC_FLAGS, *[f"-D{d}" for d in defines], *[f"-I{d}" for d in include_dirs]]
+    for src, extra in UNITS:
+        obj = os.path.join(out_dir, f".{tag}.{os.path.splitext(src)[0]}.o")
+        objs.append(obj)
+        procs.append(subprocess.Popen([hipcc, *common, *extra, "-c", "-o", obj, os.path.join(CSRC, src)]))
+    try:
+        for p in procs:
+            if p.wait() != 0:
+                raise subprocess.CalledProcessError(p.returncode, p.args)
+        tmp = os.path.join(out_dir, f".{tag}.so")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp, *objs])
+        os.replace(tmp, out_so)
+    finally:
+        for o in objs:
+            if os.path.exists(o):
+                os.remove(o)
+    return out_so

@@ -16,7 +16,6 @@ from __future__ import annotations
 
 import hashlib
 import os
-import subprocess
 import sys
 import time
 
@@ -24,7 +23,6 @@ import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared"]
 VERBOSE = False
 MAX_USER_W = 8        # nx + nu the lane-per-trajectory backward stage is built for (everything in registers)
 
@@ -265,9 +263,5 @@ def build_user_library(nx, nu, n_par, exprs, name, out_root=None, hipcc=None, fo
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, "user_gen.h"), "w") as fh:
         fh.write(generate_user_header(nx, nu, n_par, exprs, name))
-    hipcc = hipcc or os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    src = os.path.join(_HERE, "csrc", "ilqr_hip.hip")
-    tmp = so + f".{os.getpid()}.tmp"
-    subprocess.check_call([hipcc, *HIPCC_FLAGS, "-DILQR_USER_MODEL", "-DILQR_ONLY_USER", f"-I{d}", "-o", tmp, src])
-    os.replace(tmp, so)
-    return so
+    from .build import build_library
+    return build_library(so, defines=("ILQR_USER_MODEL", "ILQR_ONLY_USER"), include_dirs=(d,), hipcc=hipcc)

@@ -12,27 +12,23 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/ilqr_hip.h"
-#include "solver_device.hpp"
-#include "solve_pipeline.hpp"
-#include "team_backward.hpp"
+#define ILQR_MAIN_TU
+#include "pipeline_host.hpp"
 
 using namespace ilqr;
 
 namespace {
-
 thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, const char* a = "")
+}
+namespace ilqr {
+int fail(int code, const char* fmt, const char* a)
 {
     snprintf(g_err, sizeof(g_err), fmt, a);
     return code;
 }
-#define HIP_TRY(expr)                                                             \
-    do {                                                                          \
-        hipError_t e_ = (expr);                                                   \
-        if (e_ != hipSuccess) return fail(ILQR_E_HIP, #expr ": %s", hipGetErrorString(e_)); \
-    } while (0)
+}  // namespace ilqr
+
+namespace {
 
 struct Dev {
     ilqr_problem p;
@@ -179,163 +175,8 @@ WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
     return w;
 }
 
-// ILQR_FLAG_TIMING: a pair of events around every launch, summed per phase when the solve is over.
 thread_local ilqr_timing g_timing;
 thread_local bool g_timing_valid = false;
-thread_local std::vector<hipEvent_t> g_events;     // per host thread: each part of a solve is driven by its own thread
-
-struct PhaseTimer {
-    bool on;
-    hipStream_t st;
-    size_t used = 0;
-    std::vector<int> phase;
-    PhaseTimer(bool enable, hipStream_t s) : on(enable), st(s) {}
-    void begin(int ph)
-    {
-        if (!on) return;
-        while (g_events.size() < used + 2) {
-            hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
-            g_events.push_back(e);
-        }
-        phase.push_back(ph);
-        (void)hipEventRecord(g_events[used], st);
-    }
-    void end()
-    {
-        if (!on) return;
-        (void)hipEventRecord(g_events[used + 1], st);
-        used += 2;
-    }
-    int finish(int iterations, ilqr_timing* dst)
-    {
-        if (dst) memset(dst, 0, sizeof(*dst));
-        if (dst) dst->iterations = iterations;
-        if (!on || !dst) return ILQR_OK;
-        HIP_TRY(hipStreamSynchronize(st));
-        for (size_t i = 0; i < phase.size() && 2 * i + 1 < used + 1; ++i) {
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, g_events[2 * i], g_events[2 * i + 1]));
-            dst->ms[phase[i]] += ms;
-            dst->launches[phase[i]] += 1;
-        }
-        return ILQR_OK;
-    }
-};
-
-inline unsigned blocks_for(long n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
-
-// One part of the batch (a contiguous range of trajectories with its own slots, lists and counters) from the
-// initial rollout to the last iteration, on one stream.  Blocks the calling thread on `st` twice per solver
-// iteration to size the next launches (a few bytes read back).
-template <class M>
-int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
-{
-    PhaseTimer tm((a.flags & ILQR_FLAG_TIMING) != 0, st);
-    tm.begin(ILQR_PHASE_INIT);
-    hipLaunchKernelGGL(pipe_init_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
-    tm.end();
-    HIP_TRY(hipGetLastError());
-    // the loop test of iLQRController.py:43 before the first iteration: max|d| is +inf there
-    if (!(INFINITY > a.d_tol) || !(0 < a.max_iter)) {
-        const int status = !(INFINITY > a.d_tol) ? ILQR_EXIT_DTOL : ILQR_EXIT_MAXITER;
-        hipLaunchKernelGGL(pipe_finish_all_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a, status);
-        HIP_TRY(hipGetLastError());
-        tm.begin(ILQR_PHASE_EXPORT);
-        hipLaunchKernelGGL(pipe_export_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
-        tm.end();
-        HIP_TRY(hipGetLastError());
-        return tm.finish(0, tout);
-    }
-    // Line-search schedule after evaluation 1 (all three give bit-identical results):
-    //   default                  the next GA evaluations GA lanes per trajectory, then GB at a time, commit
-    //   ILQR_FLAG_PARALLEL_LS    evaluations 2.. sixteen at a time, commit
-    //   ILQR_FLAG_LS_SEQUENTIAL  one launch per evaluation over the compacted list of those still searching
-    constexpr int GA = 8, GB = 16;
-    int32_t h[4];
-    long count = a.B;
-    int iters_run = 0;
-    for (int iter = 1; iter <= a.max_iter && count > 0; ++iter) {
-        iters_run = iter;
-        a.count = (int)count;
-        a.iter = iter;
-        HIP_TRY(hipMemsetAsync(a.cnt, 0, 64 * sizeof(int32_t), st));
-        tm.begin(ILQR_PHASE_BACKWARD);
-        if constexpr (M::TEAM_BACKWARD) {
-            hipLaunchKernelGGL(pipe_backward_team_kernel<M>, dim3(blocks_for(count, PIPE_WG / TEAM_LANES)),
-                               dim3(PIPE_WG), 0, st, a);
-        } else {
-            hipLaunchKernelGGL(pipe_backward_kernel<M>, dim3(blocks_for(count, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
-        }
-        tm.end();
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h, a.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        const long next = h[0], nls = h[1];
-        if (nls > 0) {
-            tm.begin(ILQR_PHASE_FORWARD1);
-            hipLaunchKernelGGL(pipe_forward1_kernel<M>, dim3(blocks_for(nls, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
-            tm.end();
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(h + 2, a.cnt + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            long bound = h[2];                    // trajectories whose first candidate was rejected
-            if (bound > 0 && a.max_ls >= 2 && (a.flags & ILQR_FLAG_LS_SEQUENTIAL)) {
-                int32_t *lin = a.bt, *lout = a.bt2;
-                double alpha = 0.5;
-                for (int ls = 2; bound > 0 && ls <= a.max_ls; ++ls, alpha *= 0.5) {
-                    tm.begin(ILQR_PHASE_BACKTRACK);
-                    hipLaunchKernelGGL(pipe_forward_level_kernel<M>, dim3(blocks_for(bound, PIPE_WG)), dim3(PIPE_WG), 0,
-                                       st, a, lin, a.cnt + ls, lout, a.cnt + ls + 1, ls, alpha);
-                    tm.end();
-                    HIP_TRY(hipGetLastError());
-                    int32_t* t = lin; lin = lout; lout = t;
-                    if ((ls % 4) == 0) {     // tighten the bound now and then
-                        HIP_TRY(hipMemcpyAsync(h + 3, a.cnt + ls + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-                        HIP_TRY(hipStreamSynchronize(st));
-                        bound = h[3];
-                    }
-                }
-            } else if (bound > 0 && a.max_ls >= 2) {
-                const int32_t* lin = a.bt;
-                const int32_t* nin = a.cnt + 2;
-                bool more = true;       // can an entry still be searching after the launches so far?
-                if (!(a.flags & ILQR_FLAG_PARALLEL_LS)) {
-                    tm.begin(ILQR_PHASE_BACKTRACK);
-                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GA, false>), dim3(blocks_for(bound, 64 / GA)),
-                                       dim3(PIPE_WG), 0, st, a, lin, nin, a.bt2, a.cnt + 3);
-                    tm.end();
-                    HIP_TRY(hipGetLastError());
-                    lin = a.bt2; nin = a.cnt + 3;
-                    more = a.max_ls > GA;     // an entry that started at evaluation 1 goes on with number GA + 1
-                }
-                if (more) {
-                    tm.begin(ILQR_PHASE_BACKTRACK);
-                    // the list this stage works on is usually a fraction of `bound`: a capped grid strides over it
-                    const unsigned gb = blocks_for(bound, 64 / GB);
-                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GB, true>), dim3(gb < 4096u ? gb : 4096u),
-                                       dim3(PIPE_WG), 0, st, a, lin, nin, (int32_t*)nullptr, (int32_t*)nullptr);
-                    tm.end();
-                    HIP_TRY(hipGetLastError());
-                }
-                tm.begin(ILQR_PHASE_COMMIT);
-                hipLaunchKernelGGL(pipe_commit_kernel<M>, dim3(blocks_for(bound, PIPE_WG)), dim3(PIPE_WG), 0, st, a,
-                                   a.bt, a.cnt + 2);
-                tm.end();
-                HIP_TRY(hipGetLastError());
-            }
-        }
-        // the buffer the candidates were written to becomes the current one
-        double* t = a.TA; a.TA = a.TB; a.TB = t;
-        int32_t* ti = a.idA; a.idA = a.idB; a.idB = ti;
-        count = next;
-    }
-    tm.begin(ILQR_PHASE_EXPORT);
-    hipLaunchKernelGGL(pipe_export_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
-    tm.end();
-    HIP_TRY(hipGetLastError());
-    return tm.finish(iters_run, tout);
-}
 
 // The same pipe restricted to trajectories [lo, lo + n): every per-trajectory and per-slot pointer moves by lo.
 template <class M>

@@ -1,0 +1,12 @@
+// run_part for the car and for user-defined plants; see pipeline_host.hpp for why
+// this is a translation unit of its own.
+#include "pipeline_host.hpp"
+
+namespace ilqr {
+#ifndef ILQR_ONLY_USER
+template int run_part<CarModel>(Pipe, hipStream_t, ilqr_timing*);
+#endif
+#ifdef ILQR_USER_MODEL
+template int run_part<UserModel>(Pipe, hipStream_t, ilqr_timing*);
+#endif
+}  // namespace ilqr
