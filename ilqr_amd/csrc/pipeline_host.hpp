@@ -101,6 +101,8 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
     //   ILQR_FLAG_PARALLEL_LS    evaluations 2.. sixteen at a time, commit
     //   ILQR_FLAG_LS_SEQUENTIAL  one launch per evaluation over the compacted list of those still searching
     constexpr int GA = 8, GB = 16;
+    // side by side means GA lanes per search: affordable while that still fits the GPU in one go
+    constexpr long TAIL_COUNT = M::TEAM_BACKWARD ? 8192 : 65536;
     int32_t h[4];
     long count = a.B;
     int iters_run = 0;
@@ -108,6 +110,11 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
         iters_run = iter;
         a.count = (int)count;
         a.iter = iter;
+        // Latency-bound regime (about one wavefront per SIMD or less): fewer, wider launches per iteration.
+        // The schedule does not change any result, so neither does the threshold.
+        const bool tail = count <= TAIL_COUNT && a.max_ls >= 2 &&
+                          !(a.flags & (ILQR_FLAG_LS_SEQUENTIAL | ILQR_FLAG_PARALLEL_LS));
+        a.tail = tail ? 1 : 0;
         HIP_TRY(hipMemsetAsync(a.cnt, 0, 64 * sizeof(int32_t), st));
         tm.begin(ILQR_PHASE_BACKWARD);
         if constexpr (M::TEAM_BACKWARD) {
@@ -122,10 +129,12 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
         HIP_TRY(hipStreamSynchronize(st));
         const long next = h[0], nls = h[1];
         if (nls > 0) {
-            tm.begin(ILQR_PHASE_FORWARD1);
-            hipLaunchKernelGGL(pipe_forward1_kernel<M>, dim3(blocks_for(nls, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
-            tm.end();
-            HIP_TRY(hipGetLastError());
+            if (!tail) {
+                tm.begin(ILQR_PHASE_FORWARD1);
+                hipLaunchKernelGGL(pipe_forward1_kernel<M>, dim3(blocks_for(nls, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+                tm.end();
+                HIP_TRY(hipGetLastError());
+            }
             // Trajectories whose first candidate was rejected: the kernels below read the list's length on the
             // device; the host only needs an upper bound for the grids, and waiting for the exact number would
             // put a round trip to the host between forward1 and the backtracking kernels of every iteration.
@@ -153,7 +162,15 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
                 const int32_t* lin = a.bt;
                 const int32_t* nin = a.cnt + 2;
                 bool more = true;       // can an entry still be searching after the launches so far?
-                if (!(a.flags & ILQR_FLAG_PARALLEL_LS)) {
+                if (tail) {
+                    // one launch: GA candidates at a time until every search has stopped
+                    tm.begin(ILQR_PHASE_BACKTRACK);
+                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GA, true>), dim3(blocks_for(bound, 64 / GA)),
+                                       dim3(PIPE_WG), 0, st, a, lin, nin, (int32_t*)nullptr, (int32_t*)nullptr);
+                    tm.end();
+                    HIP_TRY(hipGetLastError());
+                    more = false;
+                } else if (!(a.flags & ILQR_FLAG_PARALLEL_LS)) {
                     tm.begin(ILQR_PHASE_BACKTRACK);
                     // grid-stride kernels: a capped grid covers a long list in several trips and costs little
                     // when the list turns out short
@@ -168,7 +185,7 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
                 if (more) {
                     tm.begin(ILQR_PHASE_BACKTRACK);
                     const unsigned gb = blocks_for(bound, 64 / GB);
-                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GB, true>), dim3(gb < 4096u ? gb : 4096u),
+                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GB, true>), dim3(gb < 1024u ? gb : 1024u),
                                        dim3(PIPE_WG), 0, st, a, lin, nin, (int32_t*)nullptr, (int32_t*)nullptr);
                     tm.end();
                     HIP_TRY(hipGetLastError());

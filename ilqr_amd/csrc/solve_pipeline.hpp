@@ -78,6 +78,7 @@ struct Pipe {
     int32_t* cnt;              // [0] slots handed out in B, [1] line-search entries, [2] rejected at alpha = 1,
                                // [3..] list lengths of the later stages
     int count;                 // running trajectories = used slots of buffer A
+    int tail;                  // few trajectories left: every search is evaluated side by side from its first candidate
     int iter;                  // 1-based number of the iteration being run
 };
 
@@ -228,16 +229,22 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
     }
     const int j = wave_append(need_ls, a.cnt + 1);
     const int ns = wave_append(cont, a.cnt + 0);
+    bool side = false;
     if (need_ls) {
         a.ls_slot[j] = s;
         a.ls_dest[j] = cont ? ns : -1;
         // A trajectory whose last search rejected alpha = 1 will most likely reject it again: its first
         // candidate is then evaluated together with the next three by the side-by-side kernel instead of
         // being computed and written on its own (same candidates, same order, same result either way).
-        const bool side_by_side = !(a.flags & ILQR_FLAG_LS_SEQUENTIAL) && a.max_ls >= 2 && a.pred[id] != 0;
-        a.ls_from[j] = side_by_side ? 1 : 2;
+        // When few trajectories are left the launches are bound by latency, not by throughput, and every
+        // search goes that way (a.tail): one kernel less per iteration.
+        side = !(a.flags & ILQR_FLAG_LS_SEQUENTIAL) && a.max_ls >= 2 && (a.tail || a.pred[id] != 0);
+        a.ls_from[j] = side ? 1 : 2;
         if (cont) a.idB[ns] = id;
     }
+    // the side-by-side entries open the list of searches that go on after their first candidate
+    const int q = wave_append(side, a.cnt + 2);
+    if (side) a.bt[q] = j;
 }
 
 __device__ __forceinline__ void record_search(const Pipe& a, int id, int ls, bool complete, double Jn)
@@ -260,9 +267,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward1_kernel(Pipe 
     const int j = blockIdx.x * PIPE_WG + threadIdx.x;
     const int nls = a.cnt[1];
     bool need_bt = false;
-    if (j < nls && a.ls_from[j] == 1) {
-        need_bt = true;         // handed to the side-by-side kernels untouched
-    } else if (j < nls) {
+    if (j < nls && a.ls_from[j] != 1) {      // (side-by-side entries are in the list already)
         const int s = a.ls_slot[j], dest = a.ls_dest[j], id = a.idA[s];
         const RecIn T = slot_T<M>(a.TA, a.cap, s);
         const Dest<M> d = make_dest<M>(a, dest, id);

@@ -510,13 +510,17 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
     }
     const int jls = wave_append(need_ls, a.cnt + 1);
     const int ns = wave_append(cont, a.cnt + 0);
+    bool side = false;
     if (need_ls) {
         a.ls_slot[jls] = s;
         a.ls_dest[jls] = cont ? ns : -1;
-        const bool side_by_side = !(a.flags & ILQR_FLAG_LS_SEQUENTIAL) && a.max_ls >= 2 && a.pred[id] != 0;
-        a.ls_from[jls] = side_by_side ? 1 : 2;
+        side = !(a.flags & ILQR_FLAG_LS_SEQUENTIAL) && a.max_ls >= 2 && (a.tail || a.pred[id] != 0);
+        a.ls_from[jls] = side ? 1 : 2;
         if (cont) a.idB[ns] = id;
     }
+    // the side-by-side entries open the list of searches that go on after their first candidate
+    const int q = wave_append(side, a.cnt + 2);
+    if (side) a.bt[q] = jls;
 }
 
 }  // namespace ilqr
