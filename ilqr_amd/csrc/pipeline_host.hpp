@@ -102,7 +102,8 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
     //   ILQR_FLAG_LS_SEQUENTIAL  one launch per evaluation over the compacted list of those still searching
     constexpr int GA = 8, GB = 16;
     // side by side means GA lanes per search: affordable while that still fits the GPU in one go
-    constexpr long TAIL_COUNT = M::TEAM_BACKWARD ? 8192 : 65536;
+    // (measured on 2^20 car solves in 3 parts: 88.3 ms with 262144, 90.2 ms with 65536, 95 ms with no limit)
+    constexpr long TAIL_COUNT = M::TEAM_BACKWARD ? 8192 : 262144;
     int32_t h[4];
     long count = a.B;
     int iters_run = 0;
