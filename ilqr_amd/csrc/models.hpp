@@ -47,6 +47,8 @@ struct CarModel {
 #define ILQR_CAR_BW 1
 #endif
     static constexpr int BACKWARD_WAVES = ILQR_CAR_BW;
+    // running trajectories (per part of a batch) below which every line search is evaluated side by side
+    static constexpr long TAIL_COUNT = 262144;
     __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
     {
         car_gen_dynamics(par, x, u, xn);
@@ -90,6 +92,7 @@ struct UserModel {
     static constexpr bool UNROLL = true;
     static constexpr bool TEAM_BACKWARD = false;
     static constexpr int BACKWARD_WAVES = 1;
+    static constexpr long TAIL_COUNT = 16384;
     static_assert(NX + NU <= 8, "the lane-per-trajectory backward stage keeps every matrix in registers");
     __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
     {
@@ -232,6 +235,7 @@ struct QuadraticRK4Model {
     static constexpr int NPAR = 1 + 2 * NX * NX + NU * NU + NX + NU;
     static constexpr bool UNROLL = UNROLL_;
     static constexpr int BACKWARD_WAVES = 1;
+    static constexpr long TAIL_COUNT = 8192;
     __device__ static const double* Qm(const double* p) { return p + 1; }
     __device__ static const double* Qf(const double* p) { return p + 1 + NX * NX; }
     __device__ static const double* Rm(const double* p) { return p + 1 + 2 * NX * NX; }
@@ -314,6 +318,7 @@ struct QuadQuatModel {
     static constexpr bool UNROLL = false;
     static constexpr bool TEAM_BACKWARD = true;      // 16 lanes per trajectory (team_backward.hpp)
     static constexpr int BACKWARD_WAVES = 1;
+    static constexpr long TAIL_COUNT = 8192;
     __device__ static const double* qd(const double* p) { return p + 1; }
     __device__ static const double* qfd(const double* p) { return p + 13; }
     __device__ static const double* rd(const double* p) { return p + 25; }

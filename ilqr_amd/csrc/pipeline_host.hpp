@@ -10,6 +10,7 @@
 // holds everything else (the C ABI, the 12-state plants with their 16-lanes-per-trajectory backward kernel).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -103,7 +104,8 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
     constexpr int GA = 8, GB = 16;
     // side by side means GA lanes per search: affordable while that still fits the GPU in one go
     // (measured on 2^20 car solves in 3 parts: 88.3 ms with 262144, 90.2 ms with 65536, 95 ms with no limit)
-    constexpr long TAIL_COUNT = M::TEAM_BACKWARD ? 8192 : 262144;
+    long TAIL_COUNT = M::TAIL_COUNT;
+    if (const char* e = getenv("ILQR_HIP_TAIL")) TAIL_COUNT = atol(e);     // for tuning
     int32_t h[4];
     long count = a.B;
     int iters_run = 0;
