@@ -15,6 +15,9 @@
 //   group<16> further candidates of those still searching, 16 at a time, cost only
 //   commit    the candidate each backtracking search stopped at is written (:66-72)
 //   export    finished trajectories, record layout -> the caller's strided arrays (:84)
+// When few trajectories are left the launches are bound by latency; then every
+// search is evaluated side by side from its first candidate by one group<8>
+// launch that repeats until all have stopped (backward, group, commit).
 //
 // State of a running trajectory (x, u) lives in one of two slot-indexed record
 // buffers (solver_device.hpp, Rec); the forward pass, which has to write the
