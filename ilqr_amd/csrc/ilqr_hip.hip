@@ -37,6 +37,14 @@ struct Dev {
 
 constexpr int WG = 64;
 
+// the parameter block of trajectory b as the problem describes it (one block for all, or one per trajectory)
+template <class M>
+__device__ __forceinline__ ParCache<M> par_of(const ilqr_problem& p, long b)
+{
+    const bool per_traj = (p.flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY) != 0;
+    return ParCache<M>(p.params, per_traj ? (long)p.stride : 1L, per_traj ? b : 0L);
+}
+
 // ---------------------------------------------------------------- kernels
 template <class M>
 __global__ __launch_bounds__(WG) void rollout_kernel(Dev a, const double* __restrict__ x0,
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(WG) void rollout_kernel(Dev a, const double* __rest
     const long st = a.p.stride;
     double xs[nx];
     for (int i = 0; i < nx; ++i) xs[i] = x0[(long)i * st + b];
-    double c = rollout_cost<M>(ParCache<M>(a.p.params).get(), xs, CLane{u + b, st}, Lane{x + b, st}, a.p.N - 1);
+    double c = rollout_cost<M>(par_of<M>(a.p, b).get(), xs, CLane{u + b, st}, Lane{x + b, st}, a.p.N - 1);
     if (J) J[b] = c;
 }
 
@@ -65,7 +73,8 @@ __global__ __launch_bounds__(WG) void eval_kernel(Dev a, const double* __restric
     const long b = (long)blockIdx.x * WG + threadIdx.x;
     if (b >= a.p.B) return;
     const long st = a.p.stride;
-    const double* par = a.p.params;
+    const ParCache<M> pc = par_of<M>(a.p, b);
+    const double* par = pc.get();
     double x[nx], u[m];
     for (int i = 0; i < nx; ++i) x[i] = xs[(long)i * st + b];
     for (int i = 0; i < m; ++i) u[i] = us[(long)i * st + b];
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(WG) void mpc_advance_kernel(Dev a, double* __restri
     double x[nx], xn[nx], u0[m];
     for (int i = 0; i < nx; ++i) x[i] = x0[(long)i * st + b];
     for (int i = 0; i < m; ++i) u0[i] = u[(long)i * st + b];
-    M::dynamics(a.p.params, x, u0, xn);
+    M::dynamics(par_of<M>(a.p, b).get(), x, u0, xn);
     for (int i = 0; i < nx; ++i) x0[(long)i * st + b] = xn[i];
     for (int k = 0; k < S - 1; ++k)
         for (int i = 0; i < m; ++i) u[(long)(k * m + i) * st + b] = u[(long)((k + 1) * m + i) * st + b];
@@ -143,6 +152,8 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
     if (p->stride < p->B) return fail(ILQR_E_BADARG, "stride must be >= B");
     if (!p->params) return fail(ILQR_E_BADARG, "params is NULL");
     if (p->max_iter < 0 || p->max_ls < 0 || p->trace_len < 0) return fail(ILQR_E_BADARG, "negative count");
+    if ((p->flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY) && d.npar > 8)
+        return fail(ILQR_E_BADARG, "ILQR_FLAG_PARAMS_PER_TRAJECTORY needs a plant with at most 8 parameters");
     if ((p->flags & ILQR_FLAG_LS_SEQUENTIAL) && p->max_ls > 60)
         return fail(ILQR_E_BADARG, "ILQR_FLAG_LS_SEQUENTIAL supports max_ls <= 60");
     return ILQR_OK;
@@ -184,6 +195,7 @@ Pipe part_of(Pipe a, long lo, long n, int part)
 {
     a.B = n;
     a.x0 += lo; a.u += lo; a.x += lo;
+    a.par += lo * a.par_pt;
     a.J0 += lo; a.J += lo; a.dmax += lo; a.maxq += lo;
     a.iters += lo; a.status += lo; a.regu_rounds += lo; a.regu_stages += lo; a.ls_total += lo;
     if (a.tr_ls) a.tr_ls += lo;
@@ -225,6 +237,9 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     memset(&a, 0, sizeof(a));
     a.N = p->N; a.max_iter = p->max_iter; a.max_ls = p->max_ls; a.trace_len = p->trace_len; a.flags = p->flags;
     a.d_tol = p->d_tol; a.B = p->B; a.cap = p->stride; a.par = p->params;
+    const bool per_traj = (p->flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY) != 0;
+    a.par_is = per_traj ? p->stride : 1;
+    a.par_pt = per_traj ? 1 : 0;
     a.x0 = x0; a.u = u; a.x = x;
     ilqr_outputs o;
     if (out) o = *out; else memset(&o, 0, sizeof(o));

@@ -698,22 +698,25 @@ __device__ __forceinline__ void store_rec(double* p, const double* v)
 // Plant parameters as the kernels read them: a small block is copied into
 // registers once per lane (a global load in the middle of a stage would make the
 // wavefront wait for every store it has in flight), a large one stays in memory.
+// A small block may also be given per trajectory (ILQR_FLAG_PARAMS_PER_TRAJECTORY):
+// parameter i of trajectory b at p[i * istride + b]; the shared block is the case
+// istride = 1, b = 0.
 template <class M, bool SMALL = (M::NPAR <= 8)>
 struct ParCache;
 template <class M>
 struct ParCache<M, true> {
     double v[M::NPAR];
-    __device__ __forceinline__ explicit ParCache(const double* p)
+    __device__ __forceinline__ explicit ParCache(const double* p, long istride = 1, long b = 0)
     {
 #pragma unroll
-        for (int i = 0; i < M::NPAR; ++i) v[i] = p[i];
+        for (int i = 0; i < M::NPAR; ++i) v[i] = p[(long)i * istride + b];
     }
     __device__ __forceinline__ const double* get() const { return v; }
 };
 template <class M>
 struct ParCache<M, false> {
     const double* p;
-    __device__ __forceinline__ explicit ParCache(const double* q) : p(q) {}
+    __device__ __forceinline__ explicit ParCache(const double* q, long = 1, long = 0) : p(q) {}
     __device__ __forceinline__ const double* get() const { return p; }
 };
 

@@ -20,4 +20,9 @@ class CarModel(Model):
         self.v_target = v_target
 
     def _param_block(self):
-        return np.array([self.r, self.v_target], dtype=np.float64)
+        """[r, v_target], or [B, 2] when either was given per trajectory (arrays of length B)."""
+        r, v = np.asarray(self.r, dtype=np.float64), np.asarray(self.v_target, dtype=np.float64)
+        if r.ndim == 0 and v.ndim == 0:
+            return np.array([r, v], dtype=np.float64)
+        r, v = np.broadcast_arrays(r.ravel() if r.ndim else r, v.ravel() if v.ndim else v)
+        return np.column_stack([r, v])

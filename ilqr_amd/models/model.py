@@ -37,6 +37,9 @@ class Model:
         """A BatchSolver bound to the current parameters (cached per (N, params))."""
         from ..batch import BatchSolver
         par = np.ascontiguousarray(self._param_block(), dtype=np.float64)
+        if par.ndim != 1:
+            raise ValueError("this plant holds one parameter set per trajectory: the single-point Model interface "
+                             "needs one set (evaluate batches through ilqr_amd.batch.BatchSolver)")
         key = (int(N), par.tobytes())
         cache = self.__dict__.setdefault("_eval_cache", {})
         if key not in cache:

@@ -84,23 +84,23 @@ class UserModel(Model):
     def trace(self):
         """(xs, us, ps, f, l, lf): the three methods run once on SymPy symbols."""
         from .. import codegen
-        return codegen.user_expressions(self.nx, self.nu, self.p.size, self._traced(0), self._traced(1),
+        return codegen.user_expressions(self.nx, self.nu, self.p.shape[-1], self._traced(0), self._traced(1),
                                         self._traced(2))
 
     def header_text(self) -> str:
         from .. import codegen
-        return codegen.generate_user_header(self.nx, self.nu, self.p.size, self.trace(), self.name)
+        return codegen.generate_user_header(self.nx, self.nu, self.p.shape[-1], self.trace(), self.name)
 
     def library_dir(self, out_root=None) -> str:
         """Directory that holds (or will hold) libilqr_user.so and user_gen.h of this plant."""
         from .. import codegen
-        return codegen.user_library_dir(codegen.user_key(self.nx, self.nu, self.p.size, self.trace()), self.name,
+        return codegen.user_library_dir(codegen.user_key(self.nx, self.nu, self.p.shape[-1], self.trace()), self.name,
                                         out_root)
 
     def build(self, out_root=None, force=False):
         """Generate and compile (or find already compiled) the solver library for this plant and bind to it."""
         from .. import codegen
-        self._library = codegen.build_user_library(self.nx, self.nu, self.p.size, self.trace(), self.name, out_root,
+        self._library = codegen.build_user_library(self.nx, self.nu, self.p.shape[-1], self.trace(), self.name, out_root,
                                                    force=force)
         self._bind()
         return self
@@ -124,7 +124,14 @@ class UserModel(Model):
         return self.p if self.p.size else np.zeros(1)
 
     def set_params(self, params):
-        p = np.asarray(params, dtype=np.float64).ravel()
-        if p.size != self.p.size:
-            raise ValueError(f"{type(self).__name__} was traced with {self.p.size} parameters, got {p.size}")
+        """New values for the numbers declared as `params`: [np] for the whole batch or [B, np], one set per
+        trajectory of the batches solved from now on (batched goals; no rebuild either way)."""
+        p = np.asarray(params, dtype=np.float64)
+        n = self.p.shape[-1]
+        if p.ndim == 2 and p.shape[1] == n and n > 0:
+            self.p = np.ascontiguousarray(p)
+            return
+        p = p.ravel()
+        if p.size != n:
+            raise ValueError(f"{type(self).__name__} was traced with {n} parameters, got {p.size}")
         self.p = p

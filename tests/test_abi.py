@@ -86,3 +86,26 @@ def test_no_cpu_device_path():
     from ilqr_amd.batch import BatchSolver
     with pytest.raises(RuntimeError):
         BatchSolver(0, [2.0, 2.0], 40, 50, device="cpu")
+
+
+def test_flag_values_match_header_and_per_trajectory_blocks_are_validated(L):
+    from ilqr_amd import _lib
+    src = open(HEADER).read()
+    for name, val in (("PARALLEL_LS", _lib.FLAG_PARALLEL_LS), ("LS_SEQUENTIAL", _lib.FLAG_LS_SEQUENTIAL),
+                      ("TIMING", _lib.FLAG_TIMING), ("SINGLE_STREAM", _lib.FLAG_SINGLE_STREAM),
+                      ("PARAMS_PER_TRAJECTORY", _lib.FLAG_PARAMS_PER_TRAJECTORY)):
+        m = re.search(r"ILQR_FLAG_%s\s*=\s*(\d+)" % name, src)
+        assert m and int(m.group(1)) == val, name
+    fake = C.c_void_p(256)
+    p = _lib.Problem(model_id=2, N=30, max_iter=5, max_ls=5, d_tol=1e-3, B=64, stride=64, params=fake, trace_len=0,
+                     flags=_lib.FLAG_PARAMS_PER_TRAJECTORY)
+    assert L.ilqr_solve_batch(C.byref(p), fake, fake, fake, None, fake, 1 << 40, None) == -1
+    assert b"at most 8 parameters" in L.ilqr_last_error()
+
+
+def test_car_parameter_block_shapes():
+    import numpy as np
+    from ilqr_amd import CarModel
+    assert CarModel(2, 2)._param_block().shape == (2,)
+    assert CarModel(np.ones(7), 2.0)._param_block().shape == (7, 2)
+    assert CarModel(2.0, np.arange(3.0))._param_block().tolist() == [[2.0, 0.0], [2.0, 1.0], [2.0, 2.0]]

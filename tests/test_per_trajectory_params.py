@@ -1,0 +1,88 @@
+"""One parameter block per trajectory (batched goals): the batched form of set_references
+(control/models/acrobot.py:101-103) / of the car's (r, v_target) (control/models/car.py:55-59).
+
+The reference solves one trajectory with one parameter set, so the expected result of a batch with mixed
+parameters is, per trajectory, the result of the same solve in a batch that shares that trajectory's set."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import _car_box, torch_gpu   # noqa: F401
+from user_models import ROVER_SP, Rover, rover_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _fields(r):
+    return dict(x=r.x.cpu().numpy(), u=r.u.cpu().numpy(), J=r.J.cpu().numpy(), iters=r.iters.cpu().numpy(),
+                status=r.status.cpu().numpy(), regu=r.regu_rounds.cpu().numpy(), ls=r.ls_total.cpu().numpy())
+
+
+def _same(a, b, idx):
+    for k in a:
+        assert np.array_equal(a[k][idx], b[k], equal_nan=True), k
+
+
+def test_car_mixed_targets_equal_the_shared_solves_bit_for_bit(torch_gpu, oracle):
+    from ilqr_amd.batch import BatchSolver
+    rng = np.random.default_rng(21)
+    B = 768
+    sets = np.array([[2.0, 2.0], [1.0, 3.0], [3.5, 1.0], [2.5, 0.5]])
+    which = rng.integers(0, len(sets), B)
+    x0, u0 = _car_box(rng, B), rng.standard_normal((B, 39, 2)) * 1e-4
+    mixed = _fields(BatchSolver(0, sets[which], 40, 50, 20, 1e-3).solve(x0, u0))
+    for g, par in enumerate(sets):
+        idx = np.where(which == g)[0]
+        shared = _fields(BatchSolver(0, par, 40, 50, 20, 1e-3).solve(x0[idx], u0[idx]))
+        _same(mixed, shared, idx)
+        # and the shared solves are the ones the checker agrees with
+        ref = oracle.solve_batch("car", par, 40, 50, 20, 1e-3, x0[idx], u0[idx])["info"]
+        calm = ref["max_abs_q"] < 1e5
+        assert calm.sum() > 20 and np.array_equal(shared["iters"][calm], ref["iters"][calm])
+    assert len(np.unique(mixed["J"].round(6))) > B // 2
+
+
+def test_car_model_with_arrays_through_the_drop_in_api(torch_gpu):
+    from ilqr_amd import CarModel, iLQR
+    rng = np.random.default_rng(5)
+    B = 64
+    r, v = rng.uniform(1.0, 3.0, B), rng.uniform(0.5, 3.0, B)
+    x0, u0 = _car_box(rng, B), rng.standard_normal((B, 39, 2)) * 1e-4
+    x, u = iLQR(CarModel(r, v), 40, 50, 20, 1e-3).run_ilqr(x0, u0.copy())
+    for b in (0, 17, 63):
+        xs, us = iLQR(CarModel(r[b], v[b]), 40, 50, 20, 1e-3).run_ilqr(x0[b], u0[b].copy())
+        assert np.array_equal(xs, x[b]) and np.array_equal(us, u[b])
+    with pytest.raises(ValueError, match="one parameter set per trajectory"):
+        CarModel(r, v).discrete_dynamics(x0[0], u0[0, 0])
+
+
+def test_user_plant_with_goals_per_trajectory(torch_gpu):
+    from ilqr_amd.iLQRController import iLQR
+    plant = Rover()
+    plant.use_library(os.path.join(plant.library_dir(), "libilqr_user.so"))
+    B = 96
+    x0, u0 = rover_inputs(B, 7)
+    rng = np.random.default_rng(8)
+    P = np.column_stack([rng.uniform(2, 4, B), rng.uniform(-1, 2, B), rng.uniform(1, 2, B), rng.uniform(0, 1, B)])
+    plant.set_params(P)
+    ctl = iLQR(plant, ROVER_SP["N"], ROVER_SP["max_iter"], ROVER_SP["max_ls"], ROVER_SP["d_tol"])
+    x, u = ctl.run_ilqr(x0, u0.copy())
+    it = ctl.info.iters.cpu().numpy()
+    for b in (0, 31, 95):
+        plant.set_params(P[b])
+        c1 = iLQR(plant, ROVER_SP["N"], ROVER_SP["max_iter"], ROVER_SP["max_ls"], ROVER_SP["d_tol"])
+        xs, us = c1.run_ilqr(x0[b], u0[b].copy())
+        assert np.array_equal(xs, x[b]) and np.array_equal(us, u[b]) and int(c1.info.iters[0]) == it[b]
+
+
+def test_large_parameter_blocks_are_refused(torch_gpu, oracle):
+    from ilqr_amd import _lib
+    from ilqr_amd.batch import BatchSolver
+    from test_gpu_parity import _cfg
+    c = _cfg(oracle, "acrobot")
+    with pytest.raises(ValueError, match="at most 8"):
+        BatchSolver(1, np.tile(c["par"], (4, 1)), 20, 5)
+    s = BatchSolver(1, c["par"], 20, 5, flags=_lib.FLAG_PARAMS_PER_TRAJECTORY)
+    with pytest.raises(RuntimeError, match="at most 8 parameters"):
+        s.solve(np.zeros((4, 4)), np.zeros((4, 19, 1)))
