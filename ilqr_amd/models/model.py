@@ -93,6 +93,14 @@ class Model:
         """model.py:39: (l_x, l_u, l_xx, l_ux, l_uu, f_x, f_u)."""
         return tuple(self._eval(x, u, ("l_x", "l_u", "l_xx", "l_ux", "l_uu", "f_x", "f_u")))
 
+    def _linearize_discrete(self, ref_state, ref_action):
+        """(A, B) of the integrator step at (ref_state, ref_action): Quadrotor_EA.py:202-204, acrobot.py
+        likewise; for the quaternion plant on the error state, G'AG and G'B (Quadrotor_Quat.py:231-238).
+        A scalar ref_action stands for that value in every channel (the reference's controllers pass 0)."""
+        u = np.array(np.broadcast_to(np.asarray(ref_action, dtype=np.float64), (self.nu,)))
+        f_x, f_u = self._eval(ref_state, u, ("f_x", "f_u"))
+        return f_x, f_u
+
     def final(self, x):
         """model.py:42: (V_x, V_xx)."""
         return tuple(self._eval(x, None, ("V_x", "V_xx")))

@@ -1,0 +1,72 @@
+"""Quaternion helpers against the reference's own outputs (tests/golden/quat_utils.npz, produced by importing
+maths/quaternions.py in tools/make_golden.py), the Riccati helpers, and the LQR controller on the GPU plants."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+def test_quaternion_helpers_match_reference_outputs():
+    from ilqr_amd.maths import quaternions as mq
+    g = load_golden("quat_utils")
+    for i, q in enumerate(g["q"]):
+        assert np.allclose(mq.hat(q), g["hat"][i], rtol=0, atol=0)
+        assert np.array_equal(mq.GetConjugate(q), g["conj"][i])
+        assert np.array_equal(mq.GetLeftMatrix(q), g["left"][i])
+        assert np.array_equal(mq.GetAttitudeJacobian(q), g["G"][i])
+        assert np.allclose(mq.QuaternionToParam(q.copy()), g["q2p"][i], rtol=1e-15, atol=0)
+        assert np.allclose(mq.QuaternionToRotation(q), g["rot"][i], rtol=0, atol=1e-15)
+    for i, phi in enumerate(g["phi"]):
+        got = mq.ParamToQuaternion(phi)
+        assert got.shape == g["p2q"][i].shape and np.allclose(got, g["p2q"][i], rtol=1e-15, atol=0)
+    np.random.seed(0)
+    for near in (False, True):
+        q = mq.SampleQuaternion(near)
+        assert q.shape == (4,) and abs(np.linalg.norm(q) - 1.0) < 1e-12
+        R = mq.QuaternionToRotation(q)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1.0) < 1e-12
+
+
+def test_riccati_helpers():
+    from ilqr_amd.lqr import dlqr, lqr
+    rng = np.random.default_rng(0)
+    A = np.eye(4) + 0.1 * rng.standard_normal((4, 4)); B = rng.standard_normal((4, 2))
+    Q = np.diag([1.0, 2.0, 3.0, 4.0]); R = np.diag([0.5, 0.1])
+    K, S = dlqr(A, B, Q, R)
+    res = A.T @ S @ A - S - A.T @ S @ B @ np.linalg.solve(R + B.T @ S @ B, B.T @ S @ A) + Q
+    assert np.abs(res).max() < 1e-8 * np.abs(S).max()
+    assert np.abs(np.linalg.eigvals(A - B @ K)).max() < 1.0
+    Kc, Sc = lqr(A - np.eye(4), B, Q, R)
+    res = (A - np.eye(4)).T @ Sc + Sc @ (A - np.eye(4)) - Sc @ B @ np.linalg.solve(R, B.T @ Sc) + Q
+    assert np.abs(res).max() < 1e-8 * np.abs(Sc).max()
+    assert np.linalg.eigvals(A - np.eye(4) - B @ Kc).real.max() < 0.0
+
+
+@pytest.mark.gpu
+def test_lqr_controller_stabilises_the_quadrotors_about_hover(oracle):
+    from ilqr_amd import QuadrotorEAModel, QuadrotorQuatModel
+    from ilqr_amd.lqr import LQRController
+    Q = np.diag([10.0] * 6 + [1.0] * 6); R = np.diag([0.1] * 4)
+    hover = np.full(4, 1.9006875)                       # QuadrotorControllers.py:210
+    for cls, kind in ((QuadrotorEAModel, "quad_ea"), (QuadrotorQuatModel, "quad_quat")):
+        plant = cls(Q, Q, R, dt=0.01, N=20)
+        nx = plant.nx
+        goal = np.zeros(nx); goal[2 if nx == 12 else 6] = 1.0
+        if nx == 13:
+            goal[0] = 1.0
+        ctl = LQRController(plant, uref=hover)
+        A, B = plant._linearize_discrete(goal, hover)
+        par = plant._param_block()
+        e = oracle.eval_point(kind, par, goal, hover)
+        if nx == 12:
+            assert np.allclose(A, e["f_x"], rtol=1e-10, atol=1e-12) and np.allclose(B, e["f_u"], rtol=1e-10, atol=1e-12)
+        K = ctl.gain(goal)
+        assert K.shape == (4, 12) and np.abs(np.linalg.eigvals(A - B @ K)).max() < 1.0
+        # closed loop on the nonlinear plant: a displaced start converges to the goal
+        x = goal.copy(); x[(0 if nx == 12 else 4)] += 0.3; x[(1 if nx == 12 else 5)] -= 0.2
+        d0 = np.linalg.norm(plant.CalcDifferentialState(x, goal))
+        for _ in range(400):
+            x = plant.discrete_dynamics(x, ctl.control(x, goal))
+        assert np.linalg.norm(plant.CalcDifferentialState(x, goal)) < 0.05 * d0
+    with pytest.raises(NotImplementedError):
+        LQRController(plant, mode="continuous")

@@ -458,7 +458,23 @@ def gen_user_rover(pool):
     run_cases("user_rover", dict(model="user", cls="Rover"), ROVER_SP, x0, u0, pool)
 
 
-GENS = dict(user_rover=gen_user_rover, car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
+def gen_quat_utils(pool):
+    """Outputs of the reference's NumPy quaternion helpers (maths/quaternions.py) on random quaternions."""
+    from maths import quaternions as rq
+    rng = np.random.default_rng(31)
+    q = rng.standard_normal((32, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    phi = rng.standard_normal((32, 3))
+    out = dict(q=q, phi=phi,
+               hat=np.stack([rq.hat(v) for v in q]), conj=np.stack([rq.GetConjugate(v) for v in q]),
+               left=np.stack([rq.GetLeftMatrix(v) for v in q]), G=np.stack([rq.GetAttitudeJacobian(v) for v in q]),
+               p2q=np.stack([rq.ParamToQuaternion(v) for v in phi]),
+               q2p=np.stack([rq.QuaternionToParam(v.copy()) for v in q]),
+               rot=np.stack([rq.QuaternionToRotation(v) for v in q]))
+    np.savez_compressed(os.path.join(OUT, "quat_utils.npz"), **out)
+    print("[golden] quat_utils: 32 quaternions", flush=True)
+
+
+GENS = dict(quat_utils=gen_quat_utils, user_rover=gen_user_rover, car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
             acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat, units=gen_units)
 
 
