@@ -396,3 +396,47 @@ def test_car_population_statistics_match_checker(torch_gpu, oracle):
     assert 0.9 < got["regu"].mean() / ref["regu_rounds"].mean() < 1.1
     assert abs(got["iters"].mean() - ref["iters"].mean()) < 0.15
     assert (got["iters"] == ref["iters"]).mean() > 0.95
+
+
+def test_full_size_batch_properties(torch_gpu, oracle):
+    """The bench workload at its full size (2^20 car solves, three concurrently running parts), checked on the
+    device through properties that need no second solver: x is bit for bit the rollout of u from x0; a sub-batch
+    solved alone gives the same bits (trajectories never interact, whatever part or slot they ran in); exit
+    statistics match the CPU checker's on a sample of the same batch."""
+    import torch
+    from bench import car_inputs
+    from ilqr_amd.batch import BatchSolver
+    B = 1 << 20
+    c = _cfg(oracle, "car")
+    x0, u0 = car_inputs(B, 0)
+    s = BatchSolver(0, c["par"], 40, 50, 20, 1e-3)
+    x0s = torch.as_tensor(np.ascontiguousarray(x0.T), device="cuda")
+    u0s = torch.as_tensor(np.ascontiguousarray(u0.transpose(1, 2, 0)), device="cuda")
+    us = u0s.clone()
+    xs, us, out = s.solve_soa(x0s, us)
+    torch.cuda.synchronize()
+    st, it = out["status"], out["iters"]
+    assert int(it.min()) >= 1 and int(it.max()) <= 50 and int(st.min()) >= 0 and int(st.max()) <= 3
+    ok = st != 3
+    assert torch.equal(xs[0], x0s)
+    # rollout property, on the device, in the strided layout
+    xr = torch.empty_like(xs); Jr = torch.empty(B, dtype=torch.float64, device="cuda")
+    import ctypes as C
+    from ilqr_amd.batch import _ptr
+    pr = s._problem(B, B)
+    s._check(s.lib.ilqr_rollout_cost(C.byref(pr), _ptr(x0s), _ptr(us), _ptr(xr), _ptr(Jr), s._stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(xr[:, :, ok], xs[:, :, ok])
+    # a sub-batch alone: same bits
+    idx = torch.arange(0, B, 257, device="cuda")[:4096]
+    u2 = u0s[:, :, idx].contiguous()
+    x2, u2, o2 = s.solve_soa(x0s[:, idx].contiguous(), u2)
+    torch.cuda.synchronize()
+    assert torch.equal(x2, xs[:, :, idx]) and torch.equal(u2, us[:, :, idx])
+    assert torch.equal(o2["iters"], it[idx]) and torch.equal(o2["J"].nan_to_num(), out["J"][idx].nan_to_num())
+    # exit statistics against the checker on the first 8192 trajectories
+    ref = oracle.solve_batch("car", c["par"], 40, 50, 20, 1e-3, x0[:8192], u0[:8192])["info"]
+    g = np.bincount(st[:8192].cpu().numpy(), minlength=4) / 8192.0
+    r = np.bincount(ref["status"], minlength=4) / 8192.0
+    assert np.abs(g - r).max() < 0.01, (g, r)
+    assert abs(float(it[:8192].double().mean()) - ref["iters"].mean()) < 0.3
