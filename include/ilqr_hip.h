@@ -57,7 +57,8 @@ typedef struct {
     double d_tol;
     int64_t B;            /* trajectories in this call */
     int64_t stride;       /* allocation stride of every strided buffer, >= B */
-    const double *params; /* device: parameter block of the model */
+    const double *params; /* device: parameter block of the model (one per trajectory with
+                             ILQR_FLAG_PARAMS_PER_TRAJECTORY) */
     int32_t trace_len;    /* rows of the optional per-iteration traces (0 = none) */
     int32_t flags;        /* ILQR_FLAG_* */
 } ilqr_problem;
@@ -66,7 +67,8 @@ typedef struct {
  * default: candidate 1 (alpha = 1) computed and written for every trajectory, except those whose previous search
  * rejected it; for the rejected and the excepted ones the next eight candidates in eight neighbouring lanes, then
  * sixteen at a time (cost only; the first one at which the reference's loop would stop wins), then one pass that
- * writes the trajectory each search ended with. */
+ * writes the trajectory each search ended with.  Once few trajectories are still running, every search goes
+ * side by side from its first candidate, eight at a time in one launch. */
 enum {
     ILQR_FLAG_NONE = 0,
     ILQR_FLAG_PARALLEL_LS = 1,   /* sixteen at a time right after alpha = 1 was rejected */
