@@ -274,7 +274,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     std::vector<hipStream_t>& streams = g_part_streams[dev];
-    while ((int)streams.size() < K - 1) {
+    while ((int)streams.size() < K) {
         hipStream_t s2;
         HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
         streams.push_back(s2);
@@ -282,9 +282,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     hipEvent_t start;
     HIP_TRY(hipEventCreateWithFlags(&start, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(start, st));
-    // part 0 runs on the caller's stream, the others on internal ones (the hardware has few queues per process)
-    auto stream_of = [&](int k) { return k == 0 ? st : streams[k - 1]; };
-    for (int k = 1; k < K; ++k) HIP_TRY(hipStreamWaitEvent(stream_of(k), start, 0));
+    for (int k = 0; k < K; ++k) HIP_TRY(hipStreamWaitEvent(streams[k], start, 0));
 
     std::vector<int> rcs(K, ILQR_OK);
     std::vector<std::string> msgs(K);
@@ -292,7 +290,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     auto work = [&](int k) {
         if (hipSetDevice(dev) != hipSuccess) { rcs[k] = ILQR_E_HIP; msgs[k] = "hipSetDevice failed in a part's thread"; return; }
         const long lo = ((a.B * k / K) + 63) / 64 * 64, hi = (k + 1 == K) ? a.B : ((a.B * (k + 1) / K) + 63) / 64 * 64;
-        rcs[k] = run_part<M>(part_of<M>(a, lo, hi - lo, k), stream_of(k), &tms[k]);
+        rcs[k] = run_part<M>(part_of<M>(a, lo, hi - lo, k), streams[k], &tms[k]);
         if (rcs[k] != ILQR_OK) msgs[k] = g_err;
     };
     std::vector<std::thread> threads;
@@ -302,13 +300,11 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
 
     int rc = ILQR_OK;
     for (int k = 0; k < K; ++k) {
-        if (k > 0) {
-            hipEvent_t done;
-            HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-            HIP_TRY(hipEventRecord(done, stream_of(k)));
-            HIP_TRY(hipStreamWaitEvent(st, done, 0));
-            HIP_TRY(hipEventDestroy(done));
-        }
+        hipEvent_t done;
+        HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(done, streams[k]));
+        HIP_TRY(hipStreamWaitEvent(st, done, 0));
+        HIP_TRY(hipEventDestroy(done));
         if (rcs[k] != ILQR_OK && rc == ILQR_OK) rc = fail(rcs[k], "%s", msgs[k].c_str());
         for (int ph = 0; ph < ILQR_PHASE_COUNT; ++ph) {
             total.ms[ph] += tms[k].ms[ph];
