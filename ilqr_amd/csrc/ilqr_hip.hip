@@ -42,7 +42,7 @@ template <class M>
 __device__ __forceinline__ ParCache<M> par_of(const ilqr_problem& p, long b)
 {
     const bool per_traj = (p.flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY) != 0;
-    return ParCache<M>(p.params, per_traj ? (long)p.stride : 1L, per_traj ? b : 0L);
+    return ParCache<M>(p.params, per_traj ? (long)p.stride : 1L, per_traj ? 1L : 0L, b);
 }
 
 // ---------------------------------------------------------------- kernels

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
     double xs[nx];
     for (int i = 0; i < nx; ++i) xs[i] = a.x0[(long)i * a.cap + b];
     const Dest<M> out{a.TA + b * Rec<M>::RT, a.cap * Rec<M>::RT};
-    const double J = rollout_cost_rec<M>(ParCache<M>(a.par, a.par_is, b * a.par_pt).get(), xs, CLane{a.u + b, a.cap}, out, S);     // iLQRController.py:27-34
+    const double J = rollout_cost_rec<M>(ParCache<M>(a.par, a.par_is, a.par_pt, b).get(), xs, CLane{a.u + b, a.cap}, out, S);     // iLQRController.py:27-34
     a.idA[b] = (int)b;
     a.J0[b] = J;
     a.J[b] = J;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
     const int it = a.iters[id] + 1;                                                  // :46
     double deltaJ = 0.0, dmax = 0.0, maxq = a.maxq[id];
     int rr = 0, rs = 0;
-    const ParCache<M> par(a.par, a.par_is, id * a.par_pt);
+    const ParCache<M> par(a.par, a.par_is, a.par_pt, id);
     const RecOut G = live ? RecOut{a.G + (long)s * Rec<M>::RG, a.cap * Rec<M>::RG} : RecOut{a.Gscratch, Rec<M>::RG};
     const bool ok = backward_pass<M>(par.get(), T, G, S, deltaJ, dmax, rr, rs, maxq, live, lds);     // :49
     if (live) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward1_kernel(Pipe 
         const RecIn T = slot_T<M>(a.TA, a.cap, s);
         const Dest<M> d = make_dest<M>(a, dest, id);
         const double J = a.J[id], deltaJ = a.dJ[s];
-        const double Jn = forward_pass<M>(ParCache<M>(a.par, a.par_is, id * a.par_pt).get(), T, slot_G<M>(a, s), 1.0, d, a.N - 1);  // :63-64
+        const double Jn = forward_pass<M>(ParCache<M>(a.par, a.par_is, a.par_pt, id).get(), T, slot_G<M>(a, s), 1.0, d, a.N - 1);  // :63-64
         const bool complete = (Jn - J <= -1e-2 * 1.0 * deltaJ) && (1 < a.max_ls);      // :66
         const bool abandon = (Jn != Jn) || (1 >= a.max_ls);                            // :67
         if (complete || abandon) {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward_level_kernel(
         const RecIn T = slot_T<M>(a.TA, a.cap, s);
         const Dest<M> d = make_dest<M>(a, dest, id);
         const double J = a.J[id], deltaJ = a.dJ[s];
-        const double Jn = forward_pass<M>(ParCache<M>(a.par, a.par_is, id * a.par_pt).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1);
+        const double Jn = forward_pass<M>(ParCache<M>(a.par, a.par_is, a.par_pt, id).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1);
         const bool complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);   // :66
         const bool abandon = (Jn != Jn) || (ls >= a.max_ls);                           // :67
         if (complete || abandon) {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_backtrack_group_kerne
             J = a.J[id];
             deltaJ = a.dJ[s];
         }
-        const ParCache<M> par(a.par, a.par_is, id * a.par_pt);
+        const ParCache<M> par(a.par, a.par_is, a.par_pt, id);
         bool pending = live;
         for (int base = first_ls; __ballot(pending) != 0ull; base += GL) {     // base differs between groups
             const int ls = base + g;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_commit_kernel(Pipe a,
     if (complete) {
         double alpha = 1.0;
         for (int i = 1; i < ls; ++i) alpha *= 0.5;
-        forward_pass<M>(ParCache<M>(a.par, a.par_is, id * a.par_pt).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1);
+        forward_pass<M>(ParCache<M>(a.par, a.par_is, a.par_pt, id).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1);
     } else {
         copy_traj<M>(T, d, a.N - 1);
     }

@@ -699,24 +699,29 @@ __device__ __forceinline__ void store_rec(double* p, const double* v)
 // registers once per lane (a global load in the middle of a stage would make the
 // wavefront wait for every store it has in flight), a large one stays in memory.
 // A small block may also be given per trajectory (ILQR_FLAG_PARAMS_PER_TRAJECTORY):
-// parameter i of trajectory b at p[i * istride + b]; the shared block is the case
-// istride = 1, b = 0.
+// parameter i of trajectory b at p[i * istride + b]; the shared block (istride = 1,
+// per_traj = 0) is read through a branch of its own so that it stays a scalar load.
 template <class M, bool SMALL = (M::NPAR <= 8)>
 struct ParCache;
 template <class M>
 struct ParCache<M, true> {
     double v[M::NPAR];
-    __device__ __forceinline__ explicit ParCache(const double* p, long istride = 1, long b = 0)
+    __device__ __forceinline__ explicit ParCache(const double* p, long istride = 1, long per_traj = 0, long b = 0)
     {
+        if (per_traj == 0) {
 #pragma unroll
-        for (int i = 0; i < M::NPAR; ++i) v[i] = p[(long)i * istride + b];
+            for (int i = 0; i < M::NPAR; ++i) v[i] = p[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < M::NPAR; ++i) v[i] = p[(long)i * istride + b];
+        }
     }
     __device__ __forceinline__ const double* get() const { return v; }
 };
 template <class M>
 struct ParCache<M, false> {
     const double* p;
-    __device__ __forceinline__ explicit ParCache(const double* q, long = 1, long = 0) : p(q) {}
+    __device__ __forceinline__ explicit ParCache(const double* q, long = 1, long = 0, long = 0) : p(q) {}
     __device__ __forceinline__ const double* get() const { return p; }
 };
 
