@@ -68,20 +68,16 @@ class BatchSolver:
 
     # ------------------------------------------------------------ parameters
     def set_params(self, params):
-        """One parameter block for the whole batch ([npar]), or one per trajectory ([B, npar], or a device
-        tensor [npar, stride] in the strided layout of the other arrays): batched goals, the batched form of
-        set_references (control/models/acrobot.py:101-103).  Per trajectory needs npar <= 8."""
-        if torch.is_tensor(params) and params.dim() == 2 and params.shape[0] == self.npar and params.is_cuda:
-            self.params, self.params_per_trajectory = params.to(torch.float64).contiguous(), True
-            return
+        """One parameter block for the whole batch ([npar]) or one per trajectory ([B, npar]): batched goals, the
+        batched form of set_references (control/models/acrobot.py:101-103)."""
         a = np.asarray(params.cpu() if torch.is_tensor(params) else params, dtype=np.float64)
         if a.ndim == 2:
             if a.shape[1] != self.npar:
                 raise ValueError(f"model {self.model_id} takes {self.npar} parameters, got {a.shape[1]} per trajectory")
-            if self.npar > 8:
-                raise ValueError("parameters per trajectory are supported for plants with at most 8 parameters")
-            self.params = torch.as_tensor(np.ascontiguousarray(a.T)).to(self.device)
+            self.params_np = np.ascontiguousarray(a)
             self.params_per_trajectory = True
+            self.params = None
+            self._params_key = None
             return
         p = torch.as_tensor(a.ravel())
         if p.numel() != self.npar:
@@ -91,20 +87,24 @@ class BatchSolver:
 
     def _problem(self, B: int, stride: int) -> _lib.Problem:
         flags = self.flags
+        par = self.params
         if self.params_per_trajectory:
-            have = self.params.shape[1]
+            have = self.params_np.shape[0]
             if have < B:
                 raise ValueError(f"{have} parameter blocks for {B} trajectories")
-            par = self.params
-            if have != stride:       # the blocks at the stride of this call (kept alive until the next call)
-                par = torch.zeros((self.npar, stride), dtype=torch.float64, device=self.device)
-                par[:, :min(have, stride)] = self.params[:, :min(have, stride)]
-            self._params_call = par
+            key = (B, stride)
+            if getattr(self, "_params_key", None) != key:
+                if self.npar <= 8:      # strided like the other arrays: [npar, stride]
+                    host = np.zeros((self.npar, stride))
+                    host[:, :B] = self.params_np[:B].T
+                else:                   # blocks one after the other: [B, npar]
+                    host = self.params_np[:B]
+                self._params_dev = torch.as_tensor(np.ascontiguousarray(host)).to(self.device)
+                self._params_key = key
+            par = self._params_dev
             flags |= _lib.FLAG_PARAMS_PER_TRAJECTORY
-            return _lib.Problem(self.model_id, self.N, self.max_iter, self.max_ls, self.d_tol, B, stride,
-                                C.c_void_p(par.data_ptr()), self.trace_len, flags)
         return _lib.Problem(self.model_id, self.N, self.max_iter, self.max_ls, self.d_tol, B, stride,
-                            C.c_void_p(self.params.data_ptr()), self.trace_len, flags)
+                            C.c_void_p(par.data_ptr()), self.trace_len, flags)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

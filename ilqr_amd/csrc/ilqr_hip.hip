@@ -42,7 +42,9 @@ template <class M>
 __device__ __forceinline__ ParCache<M> par_of(const ilqr_problem& p, long b)
 {
     const bool per_traj = (p.flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY) != 0;
-    return ParCache<M>(p.params, per_traj ? (long)p.stride : 1L, per_traj ? 1L : 0L, b);
+    if constexpr (M::NPAR <= 8) return ParCache<M>(p.params, per_traj ? (long)p.stride : 1L, per_traj ? 1L : 0L, b);
+    else if constexpr (M::TEAM_BACKWARD) return ParCache<M>(p.params);      // (per trajectory: refused by check_problem)
+    else return ParCache<M>(p.params + (per_traj ? b * M::NPAR : 0L));
 }
 
 // ---------------------------------------------------------------- kernels
@@ -152,8 +154,8 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
     if (p->stride < p->B) return fail(ILQR_E_BADARG, "stride must be >= B");
     if (!p->params) return fail(ILQR_E_BADARG, "params is NULL");
     if (p->max_iter < 0 || p->max_ls < 0 || p->trace_len < 0) return fail(ILQR_E_BADARG, "negative count");
-    if ((p->flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY) && d.npar > 8)
-        return fail(ILQR_E_BADARG, "ILQR_FLAG_PARAMS_PER_TRAJECTORY needs a plant with at most 8 parameters");
+    if ((p->flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY) && d.nx >= 12)
+        return fail(ILQR_E_BADARG, "ILQR_FLAG_PARAMS_PER_TRAJECTORY is not available for the 12-state plants");
     if ((p->flags & ILQR_FLAG_LS_SEQUENTIAL) && p->max_ls > 60)
         return fail(ILQR_E_BADARG, "ILQR_FLAG_LS_SEQUENTIAL supports max_ls <= 60");
     return ILQR_OK;
@@ -195,7 +197,7 @@ Pipe part_of(Pipe a, long lo, long n, int part)
 {
     a.B = n;
     a.x0 += lo; a.u += lo; a.x += lo;
-    a.par += lo * a.par_pt;
+    a.par += (M::NPAR > 8) ? lo * a.par_block : lo * a.par_pt;
     a.J0 += lo; a.J += lo; a.dmax += lo; a.maxq += lo;
     a.iters += lo; a.status += lo; a.regu_rounds += lo; a.regu_stages += lo; a.ls_total += lo;
     if (a.tr_ls) a.tr_ls += lo;
@@ -223,6 +225,10 @@ int parts_for(const ilqr_problem* p)
     return want;
 }
 
+// plants whose pipeline kernels also exist in the block-per-trajectory variant (large block, one lane per trajectory)
+template <class M>
+constexpr bool PT_OK = (M::NPAR > 8) && !M::TEAM_BACKWARD;
+
 // run_ilqr for the whole batch: see solve_pipeline.hpp.  A large batch is cut into parts that run the whole
 // pipeline independently, each on its own stream and driven by its own host thread: trajectories never
 // interact, and while one part is in a compute-bound phase (backward pass) another is in a memory-bound one
@@ -238,8 +244,10 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     a.N = p->N; a.max_iter = p->max_iter; a.max_ls = p->max_ls; a.trace_len = p->trace_len; a.flags = p->flags;
     a.d_tol = p->d_tol; a.B = p->B; a.cap = p->stride; a.par = p->params;
     const bool per_traj = (p->flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY) != 0;
-    a.par_is = per_traj ? p->stride : 1;
+    a.par_is = per_traj ? p->stride : 1;         // small blocks: strided like the other arrays
     a.par_pt = per_traj ? 1 : 0;
+    a.par_block = (per_traj && M::NPAR > 8) ? M::NPAR : 0;      // large blocks: one after the other
+    const bool big_pt = a.par_block != 0;
     a.x0 = x0; a.u = u; a.x = x;
     ilqr_outputs o;
     if (out) o = *out; else memset(&o, 0, sizeof(o));
@@ -266,7 +274,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     ilqr_timing total;
     memset(&total, 0, sizeof(total));
     if (K == 1) {
-        const int rc = run_part<M>(a, st, &total);
+        const int rc = big_pt ? run_part<M, PT_OK<M>>(a, st, &total) : run_part<M, false>(a, st, &total);
         if (rc == ILQR_OK && timing) { g_timing = total; g_timing_valid = true; }
         return rc;
     }
@@ -290,7 +298,8 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     auto work = [&](int k) {
         if (hipSetDevice(dev) != hipSuccess) { rcs[k] = ILQR_E_HIP; msgs[k] = "hipSetDevice failed in a part's thread"; return; }
         const long lo = ((a.B * k / K) + 63) / 64 * 64, hi = (k + 1 == K) ? a.B : ((a.B * (k + 1) / K) + 63) / 64 * 64;
-        rcs[k] = run_part<M>(part_of<M>(a, lo, hi - lo, k), streams[k], &tms[k]);
+        rcs[k] = big_pt ? run_part<M, PT_OK<M>>(part_of<M>(a, lo, hi - lo, k), streams[k], &tms[k])
+                        : run_part<M, false>(part_of<M>(a, lo, hi - lo, k), streams[k], &tms[k]);
         if (rcs[k] != ILQR_OK) msgs[k] = g_err;
     };
     std::vector<std::thread> threads;

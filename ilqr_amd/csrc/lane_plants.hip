@@ -4,9 +4,9 @@
 
 namespace ilqr {
 #ifndef ILQR_ONLY_USER
-template int run_part<CarModel>(Pipe, hipStream_t, ilqr_timing*);
+template int run_part<CarModel, false>(Pipe, hipStream_t, ilqr_timing*);
 #endif
 #ifdef ILQR_USER_MODEL
-template int run_part<UserModel>(Pipe, hipStream_t, ilqr_timing*);
+template int run_part<UserModel, false>(Pipe, hipStream_t, ilqr_timing*);
 #endif
 }  // namespace ilqr

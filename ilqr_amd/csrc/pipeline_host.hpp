@@ -78,12 +78,12 @@ inline unsigned blocks_for(long n, int per_block) { return (unsigned)((n + per_b
 // One part of the batch (a contiguous range of trajectories with its own slots, lists and counters) from the
 // initial rollout to the last iteration, on one stream.  Blocks the calling thread on `st` once per solver
 // iteration to size the next launches (a few bytes read back).
-template <class M>
+template <class M, bool PT = false>
 int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
 {
     PhaseTimer tm((a.flags & ILQR_FLAG_TIMING) != 0, st);
     tm.begin(ILQR_PHASE_INIT);
-    hipLaunchKernelGGL(pipe_init_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+    hipLaunchKernelGGL((pipe_init_kernel<M, PT>), dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
     tm.end();
     HIP_TRY(hipGetLastError());
     // the loop test of iLQRController.py:43 before the first iteration: max|d| is +inf there
@@ -124,7 +124,7 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
             hipLaunchKernelGGL(pipe_backward_team_kernel<M>, dim3(blocks_for(count, PIPE_WG / TEAM_LANES)),
                                dim3(PIPE_WG), 0, st, a);
         } else {
-            hipLaunchKernelGGL(pipe_backward_kernel<M>, dim3(blocks_for(count, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+            hipLaunchKernelGGL((pipe_backward_kernel<M, PT>), dim3(blocks_for(count, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
         }
         tm.end();
         HIP_TRY(hipGetLastError());
@@ -134,7 +134,7 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
         if (nls > 0) {
             if (!tail) {
                 tm.begin(ILQR_PHASE_FORWARD1);
-                hipLaunchKernelGGL(pipe_forward1_kernel<M>, dim3(blocks_for(nls, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+                hipLaunchKernelGGL((pipe_forward1_kernel<M, PT>), dim3(blocks_for(nls, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
                 tm.end();
                 HIP_TRY(hipGetLastError());
             }
@@ -150,7 +150,7 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
                 double alpha = 0.5;
                 for (int ls = 2; bound > 0 && ls <= a.max_ls; ++ls, alpha *= 0.5) {
                     tm.begin(ILQR_PHASE_BACKTRACK);
-                    hipLaunchKernelGGL(pipe_forward_level_kernel<M>, dim3(blocks_for(bound, PIPE_WG)), dim3(PIPE_WG), 0,
+                    hipLaunchKernelGGL((pipe_forward_level_kernel<M, PT>), dim3(blocks_for(bound, PIPE_WG)), dim3(PIPE_WG), 0,
                                        st, a, lin, a.cnt + ls, lout, a.cnt + ls + 1, ls, alpha);
                     tm.end();
                     HIP_TRY(hipGetLastError());
@@ -168,7 +168,7 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
                 if (tail) {
                     // one launch: GA candidates at a time until every search has stopped
                     tm.begin(ILQR_PHASE_BACKTRACK);
-                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GA, true>), dim3(blocks_for(bound, 64 / GA)),
+                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GA, true, PT>), dim3(blocks_for(bound, 64 / GA)),
                                        dim3(PIPE_WG), 0, st, a, lin, nin, (int32_t*)nullptr, (int32_t*)nullptr);
                     tm.end();
                     HIP_TRY(hipGetLastError());
@@ -178,7 +178,7 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
                     // grid-stride kernels: a capped grid covers a long list in several trips and costs little
                     // when the list turns out short
                     const unsigned ga = blocks_for(bound, 64 / GA);
-                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GA, false>), dim3(ga < 8192u ? ga : 8192u),
+                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GA, false, PT>), dim3(ga < 8192u ? ga : 8192u),
                                        dim3(PIPE_WG), 0, st, a, lin, nin, a.bt2, a.cnt + 3);
                     tm.end();
                     HIP_TRY(hipGetLastError());
@@ -188,13 +188,13 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
                 if (more) {
                     tm.begin(ILQR_PHASE_BACKTRACK);
                     const unsigned gb = blocks_for(bound, 64 / GB);
-                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GB, true>), dim3(gb < 1024u ? gb : 1024u),
+                    hipLaunchKernelGGL((pipe_backtrack_group_kernel<M, GB, true, PT>), dim3(gb < 1024u ? gb : 1024u),
                                        dim3(PIPE_WG), 0, st, a, lin, nin, (int32_t*)nullptr, (int32_t*)nullptr);
                     tm.end();
                     HIP_TRY(hipGetLastError());
                 }
                 tm.begin(ILQR_PHASE_COMMIT);
-                hipLaunchKernelGGL(pipe_commit_kernel<M>, dim3(blocks_for(bound, PIPE_WG)), dim3(PIPE_WG), 0, st, a,
+                hipLaunchKernelGGL((pipe_commit_kernel<M, PT>), dim3(blocks_for(bound, PIPE_WG)), dim3(PIPE_WG), 0, st, a,
                                    a.bt, a.cnt + 2);
                 tm.end();
                 HIP_TRY(hipGetLastError());
@@ -216,10 +216,10 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
 // which translation unit instantiates run_part for which plant
 #ifdef ILQR_MAIN_TU
 #ifndef ILQR_ONLY_USER
-extern template int run_part<CarModel>(Pipe, hipStream_t, ilqr_timing*);
+extern template int run_part<CarModel, false>(Pipe, hipStream_t, ilqr_timing*);
 #endif
 #ifdef ILQR_USER_MODEL
-extern template int run_part<UserModel>(Pipe, hipStream_t, ilqr_timing*);
+extern template int run_part<UserModel, false>(Pipe, hipStream_t, ilqr_timing*);
 #endif
 #endif
 

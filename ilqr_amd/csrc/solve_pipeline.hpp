@@ -58,8 +58,9 @@ struct Pipe {
     double d_tol;
     long B, cap;               // trajectories, slot capacity (= stride of the caller's arrays)
     const double* par;
-    long par_is, par_pt;       // parameter i of trajectory id at par[i * par_is + id * par_pt]: (1, 0) one block for
-                               // all, (cap, 1) per trajectory
+    long par_is, par_pt;       // small blocks: parameter i of trajectory id at par[i * par_is + id * par_pt]:
+                               // (1, 0) one block for all, (cap, 1) per trajectory
+    long par_block;            // large blocks: trajectory id's block starts at par + id * par_block (0: one for all)
     // caller buffers (indexed by trajectory id)
     const double* x0;
     double* u;
@@ -131,8 +132,20 @@ __device__ __forceinline__ Dest<M> make_dest(const Pipe& a, int dest, int id)
     return dest >= 0 ? Dest<M>{a.TB + (long)dest * Rec<M>::RT, a.cap * Rec<M>::RT} : final_dest<M>(a, id);
 }
 
+// The parameter block of trajectory `id` as the kernels hand it to the plant functions.  Small blocks are
+// copied into registers (ParCache).  Large ones stay in memory: the kernels of those plants exist twice,
+// PT = false reading the one shared block through the kernel argument (scalar loads), PT = true reading a
+// block per trajectory.
+template <class M, bool PT>
+__device__ __forceinline__ ParCache<M> params_of(const Pipe& a, long id)
+{
+    if constexpr (M::NPAR <= 8) return ParCache<M>(a.par, a.par_is, a.par_pt, id);
+    else if constexpr (PT) return ParCache<M>(a.par + id * a.par_block);
+    else return ParCache<M>(a.par);
+}
+
 // ---------------------------------------------------------------- init
-template <class M>
+template <class M, bool PT = false>
 __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
 {
     constexpr int nx = M::NX;
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
     double xs[nx];
     for (int i = 0; i < nx; ++i) xs[i] = a.x0[(long)i * a.cap + b];
     const Dest<M> out{a.TA + b * Rec<M>::RT, a.cap * Rec<M>::RT};
-    const double J = rollout_cost_rec<M>(ParCache<M>(a.par, a.par_is, a.par_pt, b).get(), xs, CLane{a.u + b, a.cap}, out, S);     // iLQRController.py:27-34
+    const double J = rollout_cost_rec<M>(params_of<M, PT>(a, b).get(), xs, CLane{a.u + b, a.cap}, out, S);     // iLQRController.py:27-34
     a.idA[b] = (int)b;
     a.J0[b] = J;
     a.J[b] = J;
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_export_kernel(Pipe a)
 }
 
 // ---------------------------------------------------------------- backward
-template <class M>
+template <class M, bool PT = false>
 __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kernel(Pipe a)
 {
     __shared__ double lds[stage_lds_doubles<M::NDX, M::NU, TermsOf<M>::type::AUX>()];
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
     const int it = a.iters[id] + 1;                                                  // :46
     double deltaJ = 0.0, dmax = 0.0, maxq = a.maxq[id];
     int rr = 0, rs = 0;
-    const ParCache<M> par(a.par, a.par_is, a.par_pt, id);
+    const ParCache<M> par = params_of<M, PT>(a, id);
     const RecOut G = live ? RecOut{a.G + (long)s * Rec<M>::RG, a.cap * Rec<M>::RG} : RecOut{a.Gscratch, Rec<M>::RG};
     const bool ok = backward_pass<M>(par.get(), T, G, S, deltaJ, dmax, rr, rs, maxq, live, lds);     // :49
     if (live) {
@@ -266,7 +279,7 @@ __device__ __forceinline__ void record_search(const Pipe& a, int id, int ls, boo
 }
 
 // ---------------------------------------------------------------- forward, alpha = 1
-template <class M>
+template <class M, bool PT = false>
 __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward1_kernel(Pipe a)
 {
     const int j = blockIdx.x * PIPE_WG + threadIdx.x;
@@ -277,7 +290,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward1_kernel(Pipe 
         const RecIn T = slot_T<M>(a.TA, a.cap, s);
         const Dest<M> d = make_dest<M>(a, dest, id);
         const double J = a.J[id], deltaJ = a.dJ[s];
-        const double Jn = forward_pass<M>(ParCache<M>(a.par, a.par_is, a.par_pt, id).get(), T, slot_G<M>(a, s), 1.0, d, a.N - 1);  // :63-64
+        const double Jn = forward_pass<M>(params_of<M, PT>(a, id).get(), T, slot_G<M>(a, s), 1.0, d, a.N - 1);  // :63-64
         const bool complete = (Jn - J <= -1e-2 * 1.0 * deltaJ) && (1 < a.max_ls);      // :66
         const bool abandon = (Jn != Jn) || (1 >= a.max_ls);                            // :67
         if (complete || abandon) {
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward1_kernel(Pipe 
 // Evaluation number `ls` (alpha = 0.5^(ls-1)) for every entry of `list_in`,
 // written; entries whose search goes on are appended to `list_out`.  (The
 // strictly sequential schedule, ILQR_FLAG_LS_SEQUENTIAL.)
-template <class M>
+template <class M, bool PT = false>
 __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward_level_kernel(Pipe a, const int32_t* __restrict__ list_in,
                                                                      const int32_t* __restrict__ n_in,
                                                                      int32_t* __restrict__ list_out,
@@ -311,7 +324,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward_level_kernel(
         const RecIn T = slot_T<M>(a.TA, a.cap, s);
         const Dest<M> d = make_dest<M>(a, dest, id);
         const double J = a.J[id], deltaJ = a.dJ[s];
-        const double Jn = forward_pass<M>(ParCache<M>(a.par, a.par_is, a.par_pt, id).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1);
+        const double Jn = forward_pass<M>(params_of<M, PT>(a, id).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1);
         const bool complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);   // :66
         const bool abandon = (Jn != Jn) || (ls >= a.max_ls);                           // :67
         if (complete || abandon) {
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward_level_kernel(
 // number and cost are left in win_ls / win_J for `commit`.  If none of the GL
 // stops: with REPEAT the same lanes go on with the next GL numbers (the last
 // number, max_ls, always stops), otherwise the entry is appended to list_out.
-template <class M, int GL, bool REPEAT>
+template <class M, int GL, bool REPEAT, bool PT = false>
 __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_backtrack_group_kernel(Pipe a, const int32_t* __restrict__ list_in,
                                                                        const int32_t* __restrict__ n_in,
                                                                        int32_t* __restrict__ list_out,
@@ -360,7 +373,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_backtrack_group_kerne
             J = a.J[id];
             deltaJ = a.dJ[s];
         }
-        const ParCache<M> par(a.par, a.par_is, a.par_pt, id);
+        const ParCache<M> par = params_of<M, PT>(a, id);
         bool pending = live;
         for (int base = first_ls; __ballot(pending) != 0ull; base += GL) {     // base differs between groups
             const int ls = base + g;
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_backtrack_group_kerne
 // One lane per entry of the list of searches whose first candidate was
 // rejected: the accepted candidate is recomputed and written, or, when the
 // search was abandoned, the trajectory is carried over unchanged (:69-72).
-template <class M>
+template <class M, bool PT = false>
 __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_commit_kernel(Pipe a, const int32_t* __restrict__ list_in,
                                                               const int32_t* __restrict__ n_in)
 {
@@ -413,7 +426,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_commit_kernel(Pipe a,
     if (complete) {
         double alpha = 1.0;
         for (int i = 1; i < ls; ++i) alpha *= 0.5;
-        forward_pass<M>(ParCache<M>(a.par, a.par_is, a.par_pt, id).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1);
+        forward_pass<M>(params_of<M, PT>(a, id).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1);
     } else {
         copy_traj<M>(T, d, a.N - 1);
     }

@@ -19,10 +19,8 @@ class QuadrotorQuatModel(QuadraticCostModel):
             if np.count_nonzero(W - np.diag(np.diag(W))):
                 raise NotImplementedError(f"{name} must be diagonal for the generated quaternion cost")
 
-    def _param_block(self):
-        return np.concatenate([[self.dt], np.diag(self.Q), np.diag(self.Qf), np.diag(self.R),
-                               np.asarray(self.xref, dtype=np.float64).ravel(),
-                               np.asarray(self.uref, dtype=np.float64).ravel()])
+    def _weights_block(self):
+        return np.concatenate([[self.dt], np.diag(self.Q), np.diag(self.Qf), np.diag(self.R)])
 
     def CalcDifferentialState(self, state, ref_state):
         """Quadrotor_Quat.py:218-228: G(state)' (state - ref_state), 12-vector."""

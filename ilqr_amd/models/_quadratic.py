@@ -23,10 +23,27 @@ class QuadraticCostModel(Model):
         self.uref = np.zeros(self.nu, dtype=np.float64)
 
     def set_references(self, xref, uref):
+        """acrobot.py:101-103.  xref [nx] and uref [nu] for every trajectory, or xref [B, nx] / uref [B, nu]:
+        references per trajectory of the batches solved from now on (batched goals)."""
         self.xref = xref
         self.uref = uref
 
+    def _references(self):
+        """(xref, uref) as arrays; both [B, .] if either was given per trajectory."""
+        xr, ur = np.asarray(self.xref, dtype=np.float64), np.asarray(self.uref, dtype=np.float64)
+        if xr.ndim == 2 or ur.ndim == 2:
+            B = xr.shape[0] if xr.ndim == 2 else ur.shape[0]
+            xr = np.broadcast_to(xr, (B, self.nx)) if xr.ndim < 2 else xr
+            ur = np.broadcast_to(ur.reshape(-1, self.nu) if ur.ndim == 2 else ur, (B, self.nu))
+            return xr, ur
+        return xr.ravel(), ur.ravel()
+
+    def _weights_block(self):
+        return np.concatenate([[self.dt], self.Q.ravel(), self.Qf.ravel(), self.R.ravel()])
+
     def _param_block(self):
-        return np.concatenate([[self.dt], self.Q.ravel(), self.Qf.ravel(), self.R.ravel(),
-                               np.asarray(self.xref, dtype=np.float64).ravel(),
-                               np.asarray(self.uref, dtype=np.float64).ravel()])
+        head = self._weights_block()
+        xr, ur = self._references()
+        if xr.ndim == 2:
+            return np.hstack([np.broadcast_to(head, (xr.shape[0], head.size)), xr, ur])
+        return np.concatenate([head, xr, ur])

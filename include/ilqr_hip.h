@@ -76,11 +76,13 @@ enum {
     ILQR_FLAG_TIMING = 4,        /* bracket every kernel launch with HIP events: see ilqr_last_timing() */
     ILQR_FLAG_SINGLE_STREAM = 8, /* run everything on the caller's stream (default: large batches are cut into
                                     parts that run concurrently on internal streams, one host thread each) */
-    /* params holds one parameter block per trajectory, strided like every other array of the call: parameter i
-     * of trajectory b at params[i * stride + b].  Batched goals: different references / targets per trajectory,
-     * the batched form of set_references (control/models/acrobot.py:101-103) and of the car's (r, v_target)
-     * (control/models/car.py:55-59).  Supported for plants whose block has at most 8 numbers (the car and
-     * user-defined plants); ILQR_E_BADARG otherwise. */
+    /* params holds one parameter block per trajectory.  Batched goals: different references / targets per
+     * trajectory, the batched form of set_references (control/models/acrobot.py:101-103) and of the car's
+     * (r, v_target) (control/models/car.py:55-59).  Layout: a plant whose block has at most 8 numbers (the car,
+     * user-defined plants) takes it strided like every other array of the call, parameter i of trajectory b at
+     * params[i * stride + b]; the acrobot, whose block is larger, takes the blocks one after the other,
+     * trajectory b's block at params + b * npar, so that its matrices stay contiguous.  Not available for the
+     * 12-state plants (ILQR_E_BADARG). */
     ILQR_FLAG_PARAMS_PER_TRAJECTORY = 16
 };
 

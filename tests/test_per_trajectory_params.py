@@ -76,13 +76,48 @@ def test_user_plant_with_goals_per_trajectory(torch_gpu):
         assert np.array_equal(xs, x[b]) and np.array_equal(us, u[b]) and int(c1.info.iters[0]) == it[b]
 
 
-def test_large_parameter_blocks_are_refused(torch_gpu, oracle):
-    from ilqr_amd import _lib
-    from ilqr_amd.batch import BatchSolver
-    from test_gpu_parity import _cfg
-    c = _cfg(oracle, "acrobot")
-    with pytest.raises(ValueError, match="at most 8"):
-        BatchSolver(1, np.tile(c["par"], (4, 1)), 20, 5)
-    s = BatchSolver(1, c["par"], 20, 5, flags=_lib.FLAG_PARAMS_PER_TRAJECTORY)
-    with pytest.raises(RuntimeError, match="at most 8 parameters"):
-        s.solve(np.zeros((4, 4)), np.zeros((4, 19, 1)))
+def test_references_per_trajectory_for_the_acrobot(torch_gpu, oracle, kind="acrobot"):
+    """set_references with one (xref, uref) per trajectory: every trajectory of the mixed batch equals, bit for
+    bit, its solve in a batch that shares its references."""
+    from ilqr_amd import Acrobot2DModel, QuadrotorEAModel, QuadrotorQuatModel, iLQR
+    from test_gpu_parity import _inputs
+    rng = np.random.default_rng(12)
+    if kind == "acrobot":
+        mk = lambda: Acrobot2DModel(np.diag([1, 1, .1, .1]), 100.0 * np.eye(4), np.array([[0.01]]), 0.05, 40)
+        N, B, sp = 40, 48, dict(max_iter=12, max_linesearch_iters=10, d_tol=1e-3)
+        refs = [(np.array([np.pi, 0, 0, 0]), np.zeros(1)), (np.array([np.pi, 0.3, 0, 0]), np.array([0.2])),
+                (np.array([3.0, -0.2, 0, 0]), np.array([-0.1]))]
+    else:
+        Q = np.diag([10.0] * 6 + [1.0] * 6); Qf = np.diag([500.0] * 3 + [100.0] * 3 + [20.0] * 6); R = np.diag([0.02] * 4)
+        cls = QuadrotorEAModel if kind == "quad_ea" else QuadrotorQuatModel
+        mk = lambda: cls(Q, Qf, R, dt=0.01, N=30)
+        N, B, sp = 30, 24, dict(max_iter=8, max_linesearch_iters=10, d_tol=5e-4)
+        nx = 12 if kind == "quad_ea" else 13
+        def ref(z, dx):
+            xr = np.zeros(nx)
+            if nx == 13:
+                xr[0] = 1.0; xr[6] = z; xr[4] = dx
+            else:
+                xr[2] = z; xr[0] = dx
+            return xr
+        refs = [(ref(1.0, 0.0), np.full(4, 1.9)), (ref(1.3, 0.2), np.full(4, 1.9)), (ref(0.8, -0.3), np.full(4, 2.0))]
+    x0, u0 = _inputs(kind, rng, B, N)
+    which = rng.integers(0, len(refs), B)
+    plant = mk()
+    plant.set_references(np.stack([refs[g][0] for g in which]), np.stack([refs[g][1] for g in which]))
+    x, u = iLQR(plant, N, **sp).run_ilqr(x0, u0.copy())
+    for g, (xr, ur) in enumerate(refs):
+        idx = np.where(which == g)[0]
+        shared = mk(); shared.set_references(xr, ur)
+        xs, us = iLQR(shared, N, **sp).run_ilqr(x0[idx], u0[idx].copy())
+        assert np.array_equal(xs, x[idx], equal_nan=True) and np.array_equal(us, u[idx], equal_nan=True), (kind, g)
+    assert not np.array_equal(x[which == 0][0], x[which == 1][0])
+
+
+def test_references_per_trajectory_are_refused_for_the_12_state_plants(torch_gpu):
+    from ilqr_amd import QuadrotorEAModel, iLQR
+    Q = np.diag([10.0] * 6 + [1.0] * 6); R = np.diag([0.02] * 4)
+    plant = QuadrotorEAModel(Q, Q, R, dt=0.01, N=10)
+    plant.set_references(np.zeros((4, 12)), np.zeros((4, 4)))
+    with pytest.raises(RuntimeError, match="12-state plants"):
+        iLQR(plant, 10, 2).run_ilqr(np.zeros((4, 12)), np.zeros((4, 9, 4)))
