@@ -214,14 +214,15 @@ Pipe part_of(Pipe a, long lo, long n, int part)
 constexpr int MAX_PARTS = 4;
 thread_local std::map<int, std::vector<hipStream_t>> g_part_streams;    // per calling thread and device
 
-int parts_for(const ilqr_problem* p)
+// `min_part`: the fewest trajectories a part may hold.
+int parts_for(const ilqr_problem* p, long min_part)
 {
     if (p->flags & ILQR_FLAG_SINGLE_STREAM) return 1;
     int want = 3;
     if (const char* e = getenv("ILQR_HIP_PARTS")) want = atoi(e);
     if (want < 1) want = 1;
     if (want > MAX_PARTS) want = MAX_PARTS;
-    while (want > 1 && p->B / want < 16384) --want;      // a part should still fill the GPU in the first iterations
+    while (want > 1 && p->B / want < min_part) --want;
     return want;
 }
 
@@ -270,7 +271,10 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     a.cnt = (int32_t*)(ws + w.cnt);
 
     const bool timing = (a.flags & ILQR_FLAG_TIMING) != 0;
-    const int K = parts_for(p);
+    // A part should still fill the GPU in the first iterations.  One lane per trajectory: 512 waves; the forward kernels
+    // keep two waves per SIMD, and thinner parts of concurrent streams were measured to land on the same SIMDs (acrobot,
+    // 65 536 trajectories: 50.1 ms in three parts, 47.0 ms in two).
+    const int K = parts_for(p, M::TEAM_BACKWARD ? 16384 : 32768);
     ilqr_timing total;
     memset(&total, 0, sizeof(total));
     if (K == 1) {

@@ -408,7 +408,7 @@ __device__ __forceinline__ void build_regularised(double* L, double coef, const 
 // Returns false on the LinAlgError cases.
 // ------------------------------------------------------------------
 template <class M>
-__device__ inline bool backward_stage(const double* par, const double* xk, const double* uk, double* Vx, double* V,
+__device__ __forceinline__ bool backward_stage(const double* par, const double* xk, const double* uk, double* Vx, double* V,
                                       double* dk, double* Kk, double& redu, int& regu_rounds, int& regu_stages,
                                       double& maxq, bool alive, double* lds)
 {
@@ -752,7 +752,7 @@ struct Dest {
 // np.max(np.linalg.norm(d, axis=1)) has).  Returns false on LinAlgError.
 // ------------------------------------------------------------------
 template <class M>
-__device__ inline bool backward_pass(const double* par, const RecIn& T, const RecOut& G, int S, double& deltaJ,
+__device__ __forceinline__ bool backward_pass(const double* par, const RecIn& T, const RecOut& G, int S, double& deltaJ,
                                      double& dmax, int& regu_rounds, int& regu_stages, double& maxq, bool active,
                                      double* lds)
 {
@@ -797,7 +797,7 @@ __device__ inline bool backward_pass(const double* par, const RecIn& T, const Re
 // the final cost).  Strided arrays in and out.
 // ------------------------------------------------------------------
 template <class M>
-__device__ inline double rollout_cost(const double* par, const double* x0, const CLane& U, const Lane& X, int S)
+__device__ __forceinline__ double rollout_cost(const double* par, const double* x0, const CLane& U, const Lane& X, int S)
 {
     constexpr int nx = M::NX, m = M::NU;
     double x[nx], xn[nx], u[m];
@@ -817,7 +817,7 @@ __device__ inline double rollout_cost(const double* par, const double* x0, const
 
 // The same with the trajectory written as T records (u copied along).
 template <class M>
-__device__ inline double rollout_cost_rec(const double* par, const double* x0, const CLane& U, const Dest<M>& out, int S)
+__device__ __forceinline__ double rollout_cost_rec(const double* par, const double* x0, const CLane& U, const Dest<M>& out, int S)
 {
     constexpr int nx = M::NX, m = M::NU;
     double x[nx], xn[nx], u[m];
@@ -840,8 +840,11 @@ __device__ inline double rollout_cost_rec(const double* par, const double* x0, c
 // (:64): u_new = u + alpha d + K dx, x_new = f(x_new, u_new).  The candidate
 // is written to `out` when WRITE; its cost is returned.
 // ------------------------------------------------------------------
+// (Always inlined, like everything a kernel here calls: a kernel's scratch size is then computed from its own
+// body.  Left out of line, the size is propagated from callee to caller through assembler symbols, and builds
+// were seen in which that came out as 0 for a callee with a 676-byte frame -- a memory aperture violation.)
 template <class M, bool WRITE = true>
-__device__ inline double forward_pass(const double* par, const RecIn& T, const RecIn& G, double alpha,
+__device__ __forceinline__ double forward_pass(const double* par, const RecIn& T, const RecIn& G, double alpha,
                                       const Dest<M>& out, int S)
 {
     constexpr int n = M::NDX, m = M::NU, nx = M::NX;
@@ -877,14 +880,14 @@ __device__ inline double forward_pass(const double* par, const RecIn& T, const R
 
 // The same evaluation without storing the candidate (cost only).
 template <class M>
-__device__ inline double forward_cost(const double* par, const RecIn& T, const RecIn& G, double alpha, int S)
+__device__ __forceinline__ double forward_cost(const double* par, const RecIn& T, const RecIn& G, double alpha, int S)
 {
     return forward_pass<M, false>(par, T, G, alpha, Dest<M>{nullptr, 0}, S);
 }
 
 // Copy of a trajectory (all T records) to `out`.
 template <class M>
-__device__ inline void copy_traj(const RecIn& T, const Dest<M>& out, int S)
+__device__ __forceinline__ void copy_traj(const RecIn& T, const Dest<M>& out, int S)
 {
     constexpr int nx = M::NX, m = M::NU;
     double xu[nx + m];
