@@ -22,7 +22,7 @@
  *
  * Pinning: the solver control flow is pinned by golden vectors produced by the
  * reference's own iLQR class (imported from the reference tree) driving NumPy
- * restatements of the plants; see tests/golden/ and tools/make_golden.py.
+ * restatements of the plants; see tests/golden/ and tests/golden/make_golden.py.
  * The car's dynamics/cost/derivatives are written here by hand, independently
  * of the generated code the HIP kernels use.  The CasADi-backed plants are
  * "parity unpinned" at model level (CasADi is not available; the reference

@@ -4,8 +4,9 @@ Nothing in the shipped package may import this module; it exists so that
   (a) the reference solver (imported from /root/reference when it is present)
       can be driven with plant models whose own source files cannot be imported
       in this image (they need pydrake / CasADi, which are not installed), and
-  (b) the symbolic expressions that the code generator prints as C come from
-      the very same arithmetic that the golden vectors were produced with.
+  (b) the plant functions the C checker is compiled with (oracle/gen/*.h,
+      printed by oracle/gen_headers.py) come from the very same arithmetic
+      that the golden vectors were produced with.
 
 Every function cites the reference lines it restates.  The arithmetic is
 written once, over a tiny "math namespace" `m` that is either NumPy or SymPy,

@@ -4,7 +4,7 @@
 Run in the build container only (needs the reference tree, default
 /root/reference, on disk; it is imported, never copied):
 
-    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [--only car_readme,...]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--only car_readme,...]
 
 What is the reference's own code here and what is not:
   * `control.iLQRController.iLQR` and `control.models.model.Model` are imported
@@ -36,7 +36,7 @@ from concurrent.futures import ProcessPoolExecutor
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = os.environ.get("ILQR_REFERENCE", "/root/reference")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, REF)

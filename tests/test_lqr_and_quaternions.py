@@ -1,5 +1,5 @@
 """Quaternion helpers against the reference's own outputs (tests/golden/quat_utils.npz, produced by importing
-maths/quaternions.py in tools/make_golden.py), the Riccati helpers, and the LQR controller on the GPU plants."""
+maths/quaternions.py in tests/golden/make_golden.py), the Riccati helpers, and the LQR controller on the GPU plants."""
 import numpy as np
 import pytest
 

@@ -1,5 +1,5 @@
 """The CPU checker (oracle/ilqr_oracle.c) against the golden vectors produced by the
-reference's own iLQR class (tools/make_golden.py).  CPU only."""
+reference's own iLQR class (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
 import pytest
 

@@ -2,7 +2,7 @@
 
 CPU tests: the printed C against the user's own Python and against SymPy's evaluation of the derivatives;
 the CPU checker compiled with that plant against a golden produced by the reference's iLQR class running the
-same Python plant (tools/make_golden.py, tests/golden/user_rover.npz).
+same Python plant (tests/golden/make_golden.py, tests/golden/user_rover.npz).
 GPU tests: the solver library compiled for the plant (built beforehand by __graft_entry__.build()) against that
 golden and against the checker.
 """

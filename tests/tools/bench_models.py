@@ -2,7 +2,7 @@
 """Throughput of the other plants at the configurations of the coverage contract (not the headline bench):
 acrobot N=100 B=65536, Euler quadrotor N=100, quaternion quadrotor N=80.  One line per plant."""
 import argparse, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from ilqr_amd.batch import BatchSolver

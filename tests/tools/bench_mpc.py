@@ -2,7 +2,7 @@
 """Closed-loop throughput of the batched receding-horizon driver (ilqr_amd/mpc.py): B loops advanced in lock step,
 state and controls resident on the GPU between solves.  Prints one JSON line per case."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from bench import car_inputs

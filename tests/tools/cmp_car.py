@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Population statistics of the headline car batch: HIP path vs the CPU checker (exit reasons, regularisation, iterations)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from bench import car_inputs

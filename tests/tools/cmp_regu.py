@@ -1,5 +1,5 @@
-import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ilqr_amd import _lib
 from ilqr_amd.batch import BatchSolver
 from oracle import c_oracle as co

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase device time of one batched solve for a plant at its contract configuration (uses ILQR_FLAG_TIMING)."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from ilqr_amd import _lib

@@ -10,16 +10,17 @@ plain C functions.  Each function is declared `ILQR_HD static inline`, where
 `ILQR_HD` expands to `__host__ __device__` under hipcc and to nothing under
 gcc, so one text serves the HIP kernels and the CPU checker.
 
-The symbolic expressions are obtained by running the arithmetic in
-oracle/models_numpy.py on SymPy symbols, so the generated C and the golden
-vectors come from one statement of each model.
+The symbolic expressions are obtained by running the plant arithmetic of
+ilqr_amd/plants.py on SymPy symbols.
 
-Outputs (identical text, two homes so that the shipped library never includes
-anything from oracle/):
+Outputs:
     ilqr_amd/csrc/gen/<model>_gen.h
-    oracle/gen/<model>_gen.h
-plus  ilqr_amd/csrc/gen/opcounts.json  (operation counts of the emitted code;
-used for the algorithmic-flop figure of the roofline report).
+    ilqr_amd/csrc/gen/opcounts.json  (operation counts of the emitted code; used for the
+                                      algorithmic-flop figure of the roofline report)
+
+The CPU checker has its own statement of the plants (written for driving the reference
+solver) and its own copies of the headers, printed by the same functions from that
+statement (`main(..., plants=..., out_dir=...)`); a test compares the two sets of headers.
 
 Usage:  python tools/gen_models.py [car acrobot quad_ea quad_quat]
 """
@@ -34,9 +35,9 @@ import sympy as sp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import models_numpy as mn  # noqa: E402
+from ilqr_amd import plants as mn  # noqa: E402  (module the gen_* functions take the plant arithmetic from)
 
-OUT_DIRS = [os.path.join(ROOT, "ilqr_amd", "csrc", "gen"), os.path.join(ROOT, "oracle", "gen")]
+OUT_DIR = os.path.join(ROOT, "ilqr_amd", "csrc", "gen")
 
 
 import ilqr_amd.codegen as _cg  # noqa: E402
@@ -207,22 +208,27 @@ def gen_quad_quat():
 GENERATORS = dict(car=gen_car, acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat)
 
 
-def main(argv):
+def main(argv, plants=None, out_dir=None):
+    """Headers for the named plants (default: all).  `plants`: another module stating the same plant functions;
+    `out_dir`: where its headers go (no operation counts are written then)."""
+    global mn
+    if plants is not None:
+        mn = plants
     which = argv[1:] or list(GENERATORS)
-    for d in OUT_DIRS:
-        os.makedirs(d, exist_ok=True)
-    ops_path = os.path.join(OUT_DIRS[0], "opcounts.json")
+    d = out_dir or OUT_DIR
+    os.makedirs(d, exist_ok=True)
+    ops_path = os.path.join(OUT_DIR, "opcounts.json")
     allops = json.load(open(ops_path)) if os.path.exists(ops_path) else {}
     for name in which:
         sys.stderr.write(f"[gen] {name}\n")
         text, ops = GENERATORS[name]()
-        for d in OUT_DIRS:
-            with open(os.path.join(d, f"{name}_gen.h"), "w") as fh:
-                fh.write(text)
+        with open(os.path.join(d, f"{name}_gen.h"), "w") as fh:
+            fh.write(text)
         allops[name] = ops
-    with open(ops_path, "w") as fh:
-        json.dump(allops, fh, indent=1, sort_keys=True)
-        fh.write("\n")
+    if out_dir is None:
+        with open(ops_path, "w") as fh:
+            json.dump(allops, fh, indent=1, sort_keys=True)
+            fh.write("\n")
 
 
 if __name__ == "__main__":
