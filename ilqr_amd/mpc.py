@@ -13,6 +13,8 @@ the state and the controls staying in device memory between solves.
 Per step:  solve (u optimised in place)  ->  apply u[0]  ->  next state.
   shift=True   next state = plant(x0, u[0]) and u[:-1] <- u[1:]      (ilqr_mpc_advance)
   shift=False  next state = x_trj[1] of the solve, u kept as it is   (Driving.ipynb)
+With `reseed_std` a loop whose plan is all zeros gets a random one before its solve, per trajectory
+(QuadrotorControllers.py:67-70: `if not utraj.any(): utraj[:] = randn(N-1, nu) * 2.0`).
 """
 from __future__ import annotations
 
@@ -22,9 +24,21 @@ from .batch import BatchSolver
 
 
 class BatchMPC:
-    def __init__(self, solver: BatchSolver, shift: bool = True):
+    def __init__(self, solver: BatchSolver, shift: bool = True, reseed_std: float | None = None,
+                 generator: torch.Generator | None = None):
+        """reseed_std: standard deviation of the plan an all-zero plan is replaced with (the reference's wrappers
+        use 2.0; None: plans are used as they are); generator: a generator on the solver's device for those draws."""
         self.solver = solver
         self.shift = bool(shift)
+        self.reseed_std = reseed_std
+        self.generator = generator
+
+    def _reseed(self, us):
+        """us [S, nu, B]: trajectories whose plan is zero everywhere get N(0, reseed_std^2) controls, the others keep
+        theirs.  No host round trip: the draw is made for the whole batch and kept where the plan was zero."""
+        dead = ~(us != 0).any(dim=0).any(dim=0)                                   # [B]
+        noise = torch.randn(us.shape, dtype=us.dtype, device=us.device, generator=self.generator) * self.reseed_std
+        us.copy_(torch.where(dead[None, None, :], noise, us))
 
     def run(self, x0, u_init, steps: int, keep_plans: bool = False) -> dict:
         """Returns trajectory-major logs on the solver's device:
@@ -48,6 +62,8 @@ class BatchMPC:
             log["u_plan"] = torch.empty((steps, B, s.N - 1, s.nu), dtype=torch.float64, device=dev)
         for t in range(steps):
             log["x"][t] = x0s.t()
+            if self.reseed_std is not None:
+                self._reseed(us)
             s.solve_soa(x0s, us, xs, out)
             log["u"][t] = us[0].t()
             log["J"][t] = out["J"]

@@ -310,6 +310,31 @@ def test_batch_mpc_follows_reference_closed_loops(torch_gpu):
         assert np.array_equal(its[:, b][st], q["iters"][b * steps:(b + 1) * steps][st]), b
 
 
+def test_batch_mpc_reseeds_all_zero_plans_per_trajectory(torch_gpu, oracle):
+    """QuadrotorControllers.py:67-70 for a batch: a loop whose plan is all zeros starts from a random plan, the others
+    keep theirs; the loops then run as if they had been given those plans."""
+    import torch
+    from ilqr_amd.batch import BatchSolver
+    from ilqr_amd.mpc import BatchMPC
+    rng = np.random.default_rng(9)
+    B, N, steps = 12, 20, 3
+    c = _cfg(oracle, "quad_quat")
+    x0, u0 = _inputs("quad_quat", rng, B, N)
+    zero = np.arange(B) % 3 == 0
+    u0[zero] = 0.0
+    s = BatchSolver(3, c["par"], N, 5, 10, 5e-4)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(77)
+    log = BatchMPC(s, shift=True, reseed_std=2.0, generator=gen).run(x0, u0, steps=steps, keep_plans=True)
+    gen2 = torch.Generator(device="cuda"); gen2.manual_seed(77)
+    noise = (torch.randn((N - 1, 4, B), dtype=torch.float64, device="cuda", generator=gen2) * 2.0).permute(2, 0, 1).cpu().numpy()
+    assert np.abs(noise[zero]).min() > 0 and abs(noise[zero].std() - 2.0) < 0.3
+    u1 = np.where(zero[:, None, None], noise, u0)
+    ref = BatchMPC(s, shift=True).run(x0, u1, steps=steps, keep_plans=True)
+    for k in ("x", "u", "J", "iters", "status", "u_plan"):
+        a, b = log[k].cpu().numpy(), ref[k].cpu().numpy()
+        assert np.array_equal(a, b, equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a, b), k
+
+
 def test_parts_on_internal_streams_do_not_change_results(torch_gpu, oracle):
     """A batch large enough to be cut into concurrently running parts (odd size, stride > B, traces on) gives
     bit-identical results to the same batch on the caller's stream alone, and leaves the padding untouched."""
