@@ -42,6 +42,9 @@ __device__ __forceinline__ void store_vec(const Lane& a, int row, const double* 
     for (int c = 0; c < C; ++c) a.st(row * C + c, v[c]);
 }
 
+template <int CNT>
+__device__ __forceinline__ void load_rec(const double* p, double* v);      // (records: see Rec below)
+
 constexpr double PIVOT_TOL = 1e-13;
 
 // Ordering point for data that the lanes of ONE wavefront exchange through LDS.
@@ -403,15 +406,23 @@ __device__ __forceinline__ void build_regularised(double* L, double coef, const 
 // Model.Q_terms (model.py:45-53), the regularisation loop (:106-115), _gains
 // (:125-129), _V_terms (:131-134) and _expected_cost_reduction (:136-137).
 // Vx and V (full V_xx) are updated in place; d_k and K_k are returned.
+// xu = [x_k, u_k] is only needed for the Q-function terms; as soon as those are
+// done the record at `next` (the stage the caller will pass next) is loaded into
+// xu, so that it arrives while the rest of the stage runs and is older than the
+// stage's stores of d_k, K_k: memory operations complete in the order they were
+// issued, and a load issued after those stores would have the next stage wait for
+// them to reach memory first.
 // Must be called by all 64 lanes of the wavefront together (`alive` = this
 // lane carries a trajectory); `lds` holds stage_lds_doubles() doubles.
 // Returns false on the LinAlgError cases.
 // ------------------------------------------------------------------
 template <class M>
-__device__ __forceinline__ bool backward_stage(const double* par, const double* xk, const double* uk, double* Vx, double* V,
+__device__ __forceinline__ bool backward_stage(const double* par, double* xu, const double* next, double* Vx, double* V,
                                       double* dk, double* Kk, double& redu, int& regu_rounds, int& regu_stages,
                                       double& maxq, bool alive, double* lds)
 {
+    const double* const xk = xu;
+    const double* const uk = xu + M::NX;
     using TR = typename TermsOf<M>::type;
     using QP = QPack<M::NDX, M::NU>;
     constexpr int n = M::NDX, m = M::NU, w = n + m;
@@ -433,6 +444,8 @@ __device__ __forceinline__ bool backward_stage(const double* par, const double* 
         ILQR_UNROLL
         for (int e = 0; e < TR::AUX; ++e) park[(NL + e) * 64] = aux[e];
     }
+    ILQR_PHASE_BARRIER();
+    load_rec<M::NX + M::NU>(next, xu);
     ILQR_PHASE_BARRIER();
 
     bool ok = true;
@@ -765,18 +778,19 @@ __device__ __forceinline__ bool backward_pass(const double* par, const RecIn& T,
     TR::final_full(par, xu, Vx, V);
     double redu = 0.0, best = -INFINITY;
     bool anynan = false, ok = true;
+    load_rec<nx + m>(T.p + (long)(S - 1) * T.ss, xu);
     // Nothing may still be in flight when the loop is entered: otherwise the wait-count bookkeeping of the
     // loop has to allow for these loads on every trip and ends up waiting for the previous stage's stores.
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
     for (int k = S - 1; k >= 0; --k) {
-        load_rec<nx + m>(T.p + (long)k * T.ss, xu);
         const bool alive = active && ok;
-        const bool good = backward_stage<M>(par, xu, xu + nx, Vx, V, dk, Kk, redu, regu_rounds, regu_stages, maxq,
-                                            alive, lds);
+        // (the stage leaves the record of stage k - 1 in xu; the last one loads its own again)
+        const bool good = backward_stage<M>(par, xu, T.p + (long)(k > 0 ? k - 1 : 0) * T.ss, Vx, V, dk, Kk, redu,
+                                            regu_rounds, regu_stages, maxq, alive, lds);
         ok = ok && good;
         // stored by every lane, whatever its state (a lane without a trajectory is given a scratch record by
-        // the caller, a failed one writes gains nobody reads): with a fixed number of stores in flight behind
-        // the load above, waiting for that load does not mean waiting for the stores to reach memory
+        // the caller, a failed one writes gains nobody reads): a fixed number of stores, all younger than the
+        // load of the next record, so that waiting for that record does not mean waiting for them
         store_rec<m + m * n>(G.p + (long)k * G.ss, g);
         if (alive && good) {
             double s = 0.0;

@@ -21,3 +21,9 @@ python tools/trace_summary.py $out/kt 3 > $out/kernel_trace_summary.txt
 python tools/trace_summary.py $out/kt1 3 > $out/kernel_trace_summary_single_stream.txt
 timeout -k 10 600 python bench.py --steps 5 > $out/bench_line.json 2> $out/bench.err
 tail -c 1500 $out/bench_line.json
+# where the wavefronts' cycles go (single stream; last, so that trouble with a counter name costs nothing else)
+cd /tmp
+ILQR_HIP_PARTS=1 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d $out/sq -- $B > $out/sq.log 2>&1
+cd $R
+python tools/sq_summary.py $out/sq > $out/sq_counters.txt
+cat $out/sq_counters.txt
