@@ -506,8 +506,16 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
             if (cstar >= 0) {
                 const double coef = regu_coef(r);
                 const double* const pl = ldsP + rank * NL;
+                // every read before the first write: the writes cannot be shown not to alias the reads, and
+                // entry by entry each read would wait for the write before it
+                double pe[NL], q0[NL];
                 ILQR_UNROLL
-                for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(coef, pl[e], park[e * 64]);
+                for (int e = 0; e < NL; ++e) pe[e] = pl[e];
+                ILQR_UNROLL
+                for (int e = 0; e < NL; ++e) q0[e] = park[e * 64];
+                ILQR_PHASE_BARRIER();
+                ILQR_UNROLL
+                for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(coef, pe[e], q0[e]);
                 // the entries above the diagonal get the mirrored entries of P (P is symmetric)
                 ILQR_UNROLL
                 for (int i = 0; i < n; ++i)
@@ -557,8 +565,14 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
                 if (lane == src) {
                     r = base + win;
                     const double cw = regu_coef(r);
+                    double pe[NL], q0[NL];
                     ILQR_UNROLL
-                    for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(cw, ldsP[e], park[e * 64]);
+                    for (int e = 0; e < NL; ++e) pe[e] = ldsP[e];
+                    ILQR_UNROLL
+                    for (int e = 0; e < NL; ++e) q0[e] = park[e * 64];
+                    ILQR_PHASE_BARRIER();
+                    ILQR_UNROLL
+                    for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(cw, pe[e], q0[e]);
                     ILQR_UNROLL
                     for (int i = 0; i < n; ++i)
                         ILQR_UNROLL
