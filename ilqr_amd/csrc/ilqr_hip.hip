@@ -43,7 +43,6 @@ __device__ __forceinline__ ParCache<M> par_of(const ilqr_problem& p, long b)
 {
     const bool per_traj = (p.flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY) != 0;
     if constexpr (M::NPAR <= 8) return ParCache<M>(p.params, per_traj ? (long)p.stride : 1L, per_traj ? 1L : 0L, b);
-    else if constexpr (M::TEAM_BACKWARD) return ParCache<M>(p.params);      // (per trajectory: refused by check_problem)
     else return ParCache<M>(p.params + (per_traj ? b * M::NPAR : 0L));
 }
 
@@ -154,8 +153,6 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
     if (p->stride < p->B) return fail(ILQR_E_BADARG, "stride must be >= B");
     if (!p->params) return fail(ILQR_E_BADARG, "params is NULL");
     if (p->max_iter < 0 || p->max_ls < 0 || p->trace_len < 0) return fail(ILQR_E_BADARG, "negative count");
-    if ((p->flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY) && d.nx >= 12)
-        return fail(ILQR_E_BADARG, "ILQR_FLAG_PARAMS_PER_TRAJECTORY is not available for the 12-state plants");
     if ((p->flags & ILQR_FLAG_LS_SEQUENTIAL) && p->max_ls > 60)
         return fail(ILQR_E_BADARG, "ILQR_FLAG_LS_SEQUENTIAL supports max_ls <= 60");
     return ILQR_OK;
@@ -226,9 +223,9 @@ int parts_for(const ilqr_problem* p, long min_part)
     return want;
 }
 
-// plants whose pipeline kernels also exist in the block-per-trajectory variant (large block, one lane per trajectory)
+// plants whose pipeline kernels also exist in the block-per-trajectory variant (large blocks)
 template <class M>
-constexpr bool PT_OK = (M::NPAR > 8) && !M::TEAM_BACKWARD;
+constexpr bool PT_OK = (M::NPAR > 8);
 
 // run_ilqr for the whole batch: see solve_pipeline.hpp.  A large batch is cut into parts that run the whole
 // pipeline independently, each on its own stream and driven by its own host thread: trajectories never

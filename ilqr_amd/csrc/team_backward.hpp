@@ -115,6 +115,17 @@ struct TeamOps<QuadraticRK4Model<12, 4, U, XD, XJ, XV>> {
             shared[e] = v;
         }
     }
+    // the same for one team's own copy (a parameter block per trajectory), filled by the team's 16 lanes
+    __device__ static void setup_team(const double* par, int j, double* shared)
+    {
+        for (int e = j; e < w * w; e += TEAM_LANES) {
+            const int rj = e / w, c = e % w;
+            double v = 0.0;
+            if (rj < n && c < n) v = M::Qm(par)[rj * n + c];
+            if (rj >= n && c >= n) v = M::Rm(par)[(rj - n) * m + (c - n)];
+            shared[e] = v;
+        }
+    }
     __device__ static void column(const double* par, const double* xu, int j, double*, double* col)
     {
         double vx[n], vu[m];
@@ -159,6 +170,7 @@ struct TeamOps<QuadQuatModel> {
     static constexpr int n = 12, m = 4, w = 16;
     static constexpr int SHARED = 0, EXTRA = 13 + 4 + 169;
     __device__ static void setup(const double*, int, double*) {}
+    __device__ static void setup_team(const double*, int, double*) {}
     // entry (t, c) of Gx [13 x 12]
     __device__ static double gx(const double* G, int t, int c)
     {
@@ -244,7 +256,8 @@ struct TeamOps<QuadQuatModel> {
     }
 };
 
-template <class M>
+// PT: one parameter block per trajectory (at a.par + id * a.par_block) instead of one for all.
+template <class M, bool PT = false>
 __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
 {
     using OPS = TeamOps<M>;
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
     static_assert(Rec<M>::RG == 52, "record sizes");
     constexpr int TEAM_ALL = TEAM_LDS + OPS::EXTRA;
     __shared__ double lds_all[(PIPE_WG / TEAM_LANES) * TEAM_ALL];
-    __shared__ double shared_all[OPS::SHARED > 0 ? OPS::SHARED : 1];
+    __shared__ double shared_all[OPS::SHARED > 0 ? (PT ? PIPE_WG / TEAM_LANES : 1) * OPS::SHARED : 1];
     const int lane = threadIdx.x & 63, team = lane / TEAM_LANES, j = lane % TEAM_LANES;
     const unsigned long long tmask = 0xFFFFull << (team * TEAM_LANES);
     double* const L = lds_all + team * TEAM_ALL;
@@ -263,13 +276,14 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
     const int s = live ? s0 : a.count - 1;      // a team without a trajectory shadows the last one
     const int S = a.N - 1;
     const int id = a.idA[s];
-    const double* const par = a.par;
+    const double* const par = PT ? a.par + (long)id * a.par_block : a.par;
     const RecIn T = slot_T<M>(a.TA, a.cap, s);
     double* const Gp = live ? a.G + (long)s * Rec<M>::RG : a.Gscratch;
     const long Gss = live ? a.cap * Rec<M>::RG : Rec<M>::RG;
     const int it = a.iters[id] + 1;                                                  // iLQRController.py:46
 
-    OPS::setup(par, lane, shared_all);
+    if constexpr (PT) OPS::setup_team(par, j, shared_all + team * OPS::SHARED);
+    else OPS::setup(par, lane, shared_all);
     wave_sync();
 
     // terminal condition (final(): V_x, V_xx at the last knot point)
@@ -299,7 +313,8 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
         for (int r = 0; r < n; ++r) L[tl::F + r * w + j] = col[r];
         // ---- l_z[j] and row j of l_zz
         double lz, lzz[w];
-        OPS::cost_row(par, xu, j, shared_all, EX, lz, lzz);
+        if constexpr (PT) OPS::cost_row(par, xu, j, shared_all + team * OPS::SHARED, EX, lz, lzz);
+        else OPS::cost_row(par, xu, j, shared_all, EX, lz, lzz);
         // ---- Q_z[j] = l_z[j] + F[:,j] . V_x ;  srow = F[:,j]' V_xx
         double qz, srow[n];
         {

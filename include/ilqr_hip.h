@@ -80,9 +80,8 @@ enum {
      * trajectory, the batched form of set_references (control/models/acrobot.py:101-103) and of the car's
      * (r, v_target) (control/models/car.py:55-59).  Layout: a plant whose block has at most 8 numbers (the car,
      * user-defined plants) takes it strided like every other array of the call, parameter i of trajectory b at
-     * params[i * stride + b]; the acrobot, whose block is larger, takes the blocks one after the other,
-     * trajectory b's block at params + b * npar, so that its matrices stay contiguous.  Not available for the
-     * 12-state plants (ILQR_E_BADARG). */
+     * params[i * stride + b]; the plants with larger blocks (acrobot, quadrotors) take the blocks one after the
+     * other, trajectory b's block at params + b * npar, so that its matrices stay contiguous. */
     ILQR_FLAG_PARAMS_PER_TRAJECTORY = 16
 };
 

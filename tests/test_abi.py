@@ -98,15 +98,6 @@ def test_flag_values_match_header_and_per_trajectory_blocks_are_validated(L):
         assert m and int(m.group(1)) == val, name
 
 
-def test_per_trajectory_blocks_are_refused_for_the_12_state_plants(L):
-    from ilqr_amd import _lib
-    fake = C.c_void_p(256)
-    p = _lib.Problem(model_id=2, N=30, max_iter=5, max_ls=5, d_tol=1e-3, B=64, stride=64, params=fake, trace_len=0,
-                     flags=_lib.FLAG_PARAMS_PER_TRAJECTORY)
-    assert L.ilqr_solve_batch(C.byref(p), fake, fake, fake, None, fake, 1 << 40, None) == -1
-    assert b"12-state plants" in L.ilqr_last_error()
-
-
 def test_car_parameter_block_shapes():
     import numpy as np
     from ilqr_amd import CarModel

@@ -76,9 +76,11 @@ def test_user_plant_with_goals_per_trajectory(torch_gpu):
         assert np.array_equal(xs, x[b]) and np.array_equal(us, u[b]) and int(c1.info.iters[0]) == it[b]
 
 
-def test_references_per_trajectory_for_the_acrobot(torch_gpu, oracle, kind="acrobot"):
-    """set_references with one (xref, uref) per trajectory: every trajectory of the mixed batch equals, bit for
-    bit, its solve in a batch that shares its references."""
+@pytest.mark.parametrize("kind", ["acrobot", "quad_ea", "quad_quat"])
+def test_references_per_trajectory(torch_gpu, oracle, kind):
+    """set_references with one (xref, uref) per trajectory (plants whose parameter block holds the weight
+    matrices too): every trajectory of the mixed batch equals, bit for bit, its solve in a batch that shares
+    its references."""
     from ilqr_amd import Acrobot2DModel, QuadrotorEAModel, QuadrotorQuatModel, iLQR
     from test_gpu_parity import _inputs
     rng = np.random.default_rng(12)
@@ -112,12 +114,3 @@ def test_references_per_trajectory_for_the_acrobot(torch_gpu, oracle, kind="acro
         xs, us = iLQR(shared, N, **sp).run_ilqr(x0[idx], u0[idx].copy())
         assert np.array_equal(xs, x[idx], equal_nan=True) and np.array_equal(us, u[idx], equal_nan=True), (kind, g)
     assert not np.array_equal(x[which == 0][0], x[which == 1][0])
-
-
-def test_references_per_trajectory_are_refused_for_the_12_state_plants(torch_gpu):
-    from ilqr_amd import QuadrotorEAModel, iLQR
-    Q = np.diag([10.0] * 6 + [1.0] * 6); R = np.diag([0.02] * 4)
-    plant = QuadrotorEAModel(Q, Q, R, dt=0.01, N=10)
-    plant.set_references(np.zeros((4, 12)), np.zeros((4, 4)))
-    with pytest.raises(RuntimeError, match="12-state plants"):
-        iLQR(plant, 10, 2).run_ilqr(np.zeros((4, 12)), np.zeros((4, 9, 4)))
