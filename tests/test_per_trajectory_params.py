@@ -114,3 +114,36 @@ def test_references_per_trajectory(torch_gpu, oracle, kind):
         xs, us = iLQR(shared, N, **sp).run_ilqr(x0[idx], u0[idx].copy())
         assert np.array_equal(xs, x[idx], equal_nan=True) and np.array_equal(us, u[idx], equal_nan=True), (kind, g)
     assert not np.array_equal(x[which == 0][0], x[which == 1][0])
+
+
+def test_closed_loops_with_a_goal_per_loop(torch_gpu, oracle):
+    """QuadrotorControllers.py:64-65 sets the goal of its one vehicle before every solve; in a batch of closed loops
+    every loop has its own.  Loops with goal A inside a mixed batch follow, bit for bit, the same loops run in a
+    batch that shares goal A."""
+    from ilqr_amd import QuadrotorQuatModel
+    from ilqr_amd.batch import BatchSolver
+    from ilqr_amd.mpc import BatchMPC
+    from test_gpu_parity import _inputs
+    rng = np.random.default_rng(31)
+    B, N, steps = 12, 20, 3
+    Q = np.diag([10.0] * 6 + [1.0] * 6); Qf = np.diag([500.0] * 3 + [100.0] * 3 + [20.0] * 6); R = np.diag([0.02] * 4)
+    goals = []
+    for z, dx in ((1.0, 0.0), (1.2, 0.3)):
+        xr = np.zeros(13); xr[0] = 1.0; xr[6] = z; xr[4] = dx
+        goals.append(xr)
+    which = np.arange(B) % 2
+    x0, u0 = _inputs("quad_quat", rng, B, N)
+    plant = QuadrotorQuatModel(Q, Qf, R, dt=0.01, N=N)
+    plant.set_references(np.stack([goals[g] for g in which]), np.full(4, 1.9))
+    s = BatchSolver(3, plant._param_block(), N, 5, 10, 5e-4)
+    log = BatchMPC(s, shift=True).run(x0, u0, steps=steps)
+    for g, xr in enumerate(goals):
+        idx = np.where(which == g)[0]
+        shared = QuadrotorQuatModel(Q, Qf, R, dt=0.01, N=N)
+        shared.set_references(xr, np.full(4, 1.9))
+        ref = BatchMPC(BatchSolver(3, shared._param_block(), N, 5, 10, 5e-4), shift=True).run(x0[idx], u0[idx], steps=steps)
+        for k in ("x", "u", "J", "iters", "status"):
+            a, b = log[k].cpu().numpy()[:, idx], ref[k].cpu().numpy()
+            assert np.array_equal(a, b, equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a, b), (g, k)
+    xs = log["x"].cpu().numpy()
+    assert not np.array_equal(xs[-1, 0], xs[-1, 1])
