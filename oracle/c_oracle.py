@@ -27,7 +27,7 @@ INFO_DTYPE = np.dtype([
 
 
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(_LIB_PATH):
+    if force or not os.path.exists(_LIB_PATH) or not os.path.exists(os.path.join(_HERE, "_build", "libeigvals_lapack.so")):
         subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
     return _LIB_PATH
 
@@ -42,8 +42,9 @@ def build_user(header_dir: str, out_dir: str = None) -> str:
     out = os.path.join(out_dir, "libilqr_oracle_user.so")
     src = os.path.join(_HERE, "ilqr_oracle.c")
     hdr = os.path.join(header_dir, "user_gen.h")
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-fopenmp",
+    deps = [src, hdr, os.path.join(_HERE, "eigvals_lapack.h"), os.path.join(_HERE, "ilqr_oracle.h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-fPIC", "-fopenmp",
                                "-Wno-unused-function", "-DORACLE_USER_MODEL", f"-I{header_dir}", f"-I{_HERE}",
                                "-shared", "-o", out, src, "-lm"])
     return out
@@ -66,6 +67,8 @@ def lib(path=None):
         L.ilqr_oracle_eval.argtypes = [C.c_int] + [dp] * 15
         L.ilqr_oracle_has_negative_eig.restype = C.c_int
         L.ilqr_oracle_has_negative_eig.argtypes = [dp, C.c_int, dp]
+        L.ilqr_oracle_has_negative_eig_ldl.restype = C.c_int
+        L.ilqr_oracle_has_negative_eig_ldl.argtypes = [dp, C.c_int, dp]
         L.ilqr_oracle_unit_qterms.restype = None
         L.ilqr_oracle_unit_qterms.argtypes = [C.c_int, C.c_int] + [dp] * 14
         L.ilqr_oracle_unit_gains_vterms.restype = C.c_int
@@ -124,10 +127,12 @@ def eval_point(model, par, x, u, library=None):
     return out
 
 
-def has_negative_eig(Q):
+def has_negative_eig(Q, rule="lapack"):
+    """np.any(np.linalg.eigvals(Q) < 0) by the checker: LAPACK restated (default) or the older LDL^T rule."""
     Q = np.ascontiguousarray(Q, dtype=np.float64)
     W = np.zeros_like(Q)
-    return lib().ilqr_oracle_has_negative_eig(_p(Q), Q.shape[0], _p(W))
+    f = lib().ilqr_oracle_has_negative_eig if rule == "lapack" else lib().ilqr_oracle_has_negative_eig_ldl
+    return f(_p(Q), Q.shape[0], _p(W))
 
 
 # parameter-block packers (layouts documented in oracle/ilqr_oracle.h)

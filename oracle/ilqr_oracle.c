@@ -28,18 +28,15 @@
  * "parity unpinned" at model level (CasADi is not available; the reference
  * stores none of their outputs).
  *
- * One deliberate, documented difference: the reference decides whether to
- * regularise with `np.any(np.linalg.eigvals(Q) < 0)` (LAPACK dgeev on the
- * general matrix, iLQRController.py:110).  Here, and in the HIP kernels, the
- * decision is an unpivoted LDL^T of the lower triangle of Q with deflation of
- * (numerically) zero pivots (has_negative_eig()).  The two agree whenever
- * Q is symmetric to rounding and its smallest eigenvalue is resolved
- * (|lambda_min| >> eps*|Q|); they can differ on solves whose matrices have
- * already blown up to ~1e16 and lost symmetry, where the reference's own
- * result is rounding noise.  Such solves are identified by `max_abs_q`.
+ * `np.any(np.linalg.eigvals(Q) < 0)` (iLQRController.py:110) is LAPACK's DGEEV on the general
+ * matrix; eigvals_lapack.h restates it routine by routine (DGEBAL, DGEHD2, DLAHQR, DLANV2 and the
+ * BLAS calls inside them, in the order the OpenBLAS inside NumPy evaluates them), and on the
+ * (matrix, verdict) pairs recorded from the reference (tests/golden/eig_decisions.npz) it gives
+ * LAPACK's verdict every time.  The cheaper unpivoted LDL^T rule the checker used before is kept
+ * as ilqr_oracle_has_negative_eig_ldl() so that tests can score it against the same pairs.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no FMA contraction,
- * like NumPy scalar arithmetic).
+ * like NumPy scalar arithmetic; the fused multiply-adds of the BLAS kernels are written out as fma()).
  */
 #include <float.h>
 #include <math.h>
@@ -47,6 +44,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "eigvals_lapack.h"
 #include "ilqr_oracle.h"
 #include "oracle_models.h"
 
@@ -88,18 +86,15 @@ static void full_hessian(const double *Qxx, const double *Qux, const double *Quu
     }
 }
 
-/* Stand-in for `np.any(np.linalg.eigvals(Q) < 0)` (iLQRController.py:110).
- * Right-looking LDL^T on the lower triangle, natural order, no pivoting.
+/* The rule used before the LAPACK restatement, kept for scoring: `np.any(np.linalg.eigvals(Q) < 0)` decided by a
+ * right-looking LDL^T on the lower triangle, natural order, no pivoting.
  *   pivot < -tol*acc_j                  -> a negative eigenvalue exists
  *   |pivot| <= tol*acc_j, column ~ 0    -> zero eigenvalue, deflate, go on
  *   |pivot| <= tol*acc_j, column != 0   -> indefinite 2x2 minor -> negative
  * acc_j = |Q_jj| + sum_k |l_jk^2 d_k| is the size of the terms pivot j is the difference
  * of, tol = ILQR_PIVOT_TOL: a pivot that cancelled to 1e-13 of them is rounding noise.
- * (With tol = 0 a Q dominated by regu*[fx fu]'[fx fu], which is rank deficient, keeps
- * the same noise sign through every further doubling of regu.)
- * Returns 1 = negative eigenvalue, 0 = none, -1 = Q not finite (NumPy raises
- * LinAlgError there). `W` is scratch of w*w doubles. */
-int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W)
+ * Returns 1 = negative eigenvalue, 0 = none, -1 = Q not finite. `W` is scratch of w*w doubles. */
+int ilqr_oracle_has_negative_eig_ldl(const double *Q, int w, double *W)
 {
     double acc[ILQR_MAX_NDX + ILQR_MAX_NU];   /* |Q_jj| + sum of |l_jk^2 d_k|: the magnitudes pivot j is a difference of */
     for (int i = 0; i < w * w; ++i) {
@@ -128,6 +123,24 @@ int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W)
         }
     }
     return 0;
+}
+
+/* `np.any(np.linalg.eigvals(Q) < 0)` (iLQRController.py:110): the eigenvalues DGEEV computes for the row-major
+ * w x w matrix Q, compared with zero the way NumPy compares (complex numbers order by real part, then imaginary).
+ * Returns 1 = some eigenvalue is negative, 0 = none, -1 = Q not finite or the QR iteration did not converge
+ * (NumPy raises LinAlgError in both cases). `W` is scratch of w*w doubles. */
+int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W)
+{
+    double wr[EIG_MAXN], wi[EIG_MAXN];
+    for (int i = 0; i < w; ++i)
+        for (int j = 0; j < w; ++j) {
+            if (!isfinite(Q[i * w + j])) return -1;
+            W[i + j * w] = Q[i * w + j];      /* column-major copy of Q itself, as NumPy hands it to LAPACK */
+        }
+    if (eig_geev_n(w, W, w, wr, wi) != 0) return -1;
+    int neg = 0;
+    for (int i = 0; i < w; ++i) neg = neg || (wr[i] < 0.0) || (wr[i] == 0.0 && wi[i] < 0.0);
+    return neg;
 }
 
 /* np.linalg.inv for m <= ILQR_MAX_NU: Gauss-Jordan with partial pivoting.
@@ -313,16 +326,12 @@ static int backward_pass(const ilqr_oracle_model *M, const double *par, const do
         /* regularisation loop, iLQRController.py:106-115:
          *   while any(eigvals(Q) < 0): Q += (regu*[fx fu])'[fx fu]; regu *= 2   with regu = 0.1 * 2^r.
          * Because regu is 0.1 times a power of two, the r-th update is exactly 2^r * P0 with
-         * P0 = (0.1*[fx fu])'[fx fu] evaluated once in the reference's operation order.
-         * Rounds 1..ILQR_REGU_EXACT accumulate those updates one by one, exactly like the
-         * reference.  Beyond that (only ill-conditioned solves get there) the accumulated
-         * matrix is formed directly, Q(r) = Q(EXACT) + (2^r - 2^EXACT) * P0, which equals the
-         * running sum up to rounding; the scan over r and the stopping rule are unchanged. */
+         * P0 = (0.1*[fx fu])'[fx fu] evaluated once in the reference's operation order; the updates are
+         * accumulated one round after the other, like the reference's in-place additions. */
         full_hessian(Qxx, Qux, Quu, Q, n, nu);
         int r = 0;
         int have_p = 0;
         double Pxx[ILQR_MAX_NDX * ILQR_MAX_NDX], Pux[ILQR_MAX_NU * ILQR_MAX_NDX], Puu[ILQR_MAX_NU * ILQR_MAX_NU];
-        double Bxx[ILQR_MAX_NDX * ILQR_MAX_NDX], Bux[ILQR_MAX_NU * ILQR_MAX_NDX], Buu[ILQR_MAX_NU * ILQR_MAX_NU];
         for (;;) {
             for (int i = 0; i < w * w; ++i) {
                 double a = fabs(Q[i]);
@@ -353,22 +362,9 @@ static int backward_pass(const ilqr_oracle_model *M, const double *par, const do
                     }
                 }
             }
-            if (r < ILQR_REGU_EXACT) {
-                const double pw = ldexp(1.0, r);
-                for (int i = 0; i < n * n; ++i) Qxx[i] += pw * Pxx[i];
-                for (int i = 0; i < nu * nu; ++i) Quu[i] += pw * Puu[i];
-                for (int i = 0; i < nu * n; ++i) Qux[i] += pw * Pux[i];
-                if (r + 1 == ILQR_REGU_EXACT) {
-                    memcpy(Bxx, Qxx, sizeof(double) * n * n);
-                    memcpy(Bux, Qux, sizeof(double) * nu * n);
-                    memcpy(Buu, Quu, sizeof(double) * nu * nu);
-                }
-            } else {
-                const double coef = ldexp(1.0, r + 1) - ldexp(1.0, ILQR_REGU_EXACT);
-                for (int i = 0; i < n * n; ++i) Qxx[i] = Bxx[i] + coef * Pxx[i];
-                for (int i = 0; i < nu * nu; ++i) Quu[i] = Buu[i] + coef * Puu[i];
-                for (int i = 0; i < nu * n; ++i) Qux[i] = Bux[i] + coef * Pux[i];
-            }
+            for (int i = 0; i < n * n; ++i) Qxx[i] += ldexp(Pxx[i], r);
+            for (int i = 0; i < nu * nu; ++i) Quu[i] += ldexp(Puu[i], r);
+            for (int i = 0; i < nu * n; ++i) Qux[i] += ldexp(Pux[i], r);
             full_hessian(Qxx, Qux, Quu, Q, n, nu);
             r += 1;
             info->regu_rounds += 1;

@@ -7,8 +7,6 @@
 #define ILQR_MAX_NDX 16
 #define ILQR_MAX_NU 4
 #define ILQR_TRACE_MAX 64
-/* regularisation rounds accumulated one by one, as the reference does (see backward_pass) */
-#define ILQR_REGU_EXACT 12
 #ifndef ILQR_PIVOT_TOL
 #define ILQR_PIVOT_TOL 1e-13
 #endif
@@ -64,7 +62,8 @@ int ilqr_oracle_solve(const ilqr_oracle_model *M, const double *par, int N, int 
 int ilqr_oracle_solve_batch(int model_id, const double *par, int N, int max_iter, int max_ls, double d_tol, long B,
                             const double *x0, double *u, double *x, ilqr_oracle_info *info, int nthreads);
 const ilqr_oracle_model *ilqr_oracle_get_model(int model_id);
-int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W);
+int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W);      /* LAPACK restated */
+int ilqr_oracle_has_negative_eig_ldl(const double *Q, int w, double *W);  /* the LDL^T rule, for scoring */
 void ilqr_oracle_model_dims(int model_id, int *nx, int *nu, int *ndx, int *npar);
 /* Diagnostics: copies the histogram of regularisation rounds per backward stage into out64 (if not NULL),
  * then, when enable >= 0, clears it and switches the counting on (1) or off (0). */
