@@ -23,7 +23,9 @@ FLAG_PARAMS_PER_TRAJECTORY = 16
 PHASES = ("init", "backward", "forward1", "backtrack", "commit", "export")
 
 EXPORTS = ("ilqr_model_info", "ilqr_workspace_bytes", "ilqr_solve_batch", "ilqr_rollout_cost",
-           "ilqr_model_eval", "ilqr_mpc_advance", "ilqr_last_timing", "ilqr_last_error", "ilqr_version")
+           "ilqr_model_eval", "ilqr_mpc_advance", "ilqr_last_timing", "ilqr_last_error", "ilqr_version",
+           "ilqr_solve_batch_static")
+STATIC_WORKSPACE_BYTES = 32 << 20
 
 _dp = C.c_void_p  # device pointers travel as plain addresses
 
@@ -66,6 +68,8 @@ def lib(path=None):
     L.ilqr_workspace_bytes.argtypes = [C.POINTER(Problem)]
     L.ilqr_solve_batch.restype = C.c_int
     L.ilqr_solve_batch.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, C.POINTER(Outputs), _dp, C.c_size_t, _dp]
+    L.ilqr_solve_batch_static.restype = C.c_int
+    L.ilqr_solve_batch_static.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, C.POINTER(Outputs), _dp]
     L.ilqr_rollout_cost.restype = C.c_int
     L.ilqr_rollout_cost.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, _dp, _dp]
     L.ilqr_model_eval.restype = C.c_int

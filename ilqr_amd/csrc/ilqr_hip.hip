@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -327,6 +328,31 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     return rc;
 }
 
+// ---------------------------------------------------------------- built-in workspace (ilqr_solve_batch_static)
+// The workspace of a solve (slot buffers, lists, counters: ws_layout) inside the library's own device memory, for
+// callers that may not allocate.  The array's name is only a handle in host code: its address on a device comes
+// from hipGetSymbolAddress, once per device with that device current, and host code uses that pointer from then on.
+static __device__ __align__(256) unsigned char scratch[ILQR_STATIC_WORKSPACE_BYTES];
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[MAX_DEVICES] = {};
+
+int static_workspace(void** ptr)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(ILQR_E_BADARG, "device index beyond the library's table");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* q = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&q, HIP_SYMBOL(scratch)));
+        if (!q) return fail(ILQR_E_HIP, "hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = q;
+    }
+    *ptr = g_scratch_ptr[dev];
+    return ILQR_OK;
+}
+
 template <class F>
 int dispatch(int model_id, F&& f)
 {
@@ -391,6 +417,33 @@ int ilqr_solve_batch(const ilqr_problem* p, const double* x0, double* u, double*
     return dispatch(p->model_id, [&](auto M) {
         using Mt = decltype(M);
         return run_pipeline<Mt>(p, x0, u, x, out, (char*)workspace, w, s);
+    });
+}
+
+int ilqr_solve_batch_static(const ilqr_problem* p, const double* x0, double* u, double* x, const ilqr_outputs* out,
+                            void* stream)
+{
+    ModelDims d;
+    int rc = check_problem(p, d);
+    if (rc) return rc;
+    if (!x0 || !u || !x) return fail(ILQR_E_BADARG, "x0, u and x must be non-NULL");
+    if (p->stride > 0x7fffffffL) return fail(ILQR_E_BADARG, "stride must fit in 31 bits");
+    if (p->flags & ILQR_FLAG_TIMING) return fail(ILQR_E_BADARG, "ILQR_FLAG_TIMING creates events: not available here");
+    const WsLayout w = ws_layout(p, d);
+    if (w.total > (size_t)ILQR_STATIC_WORKSPACE_BYTES) {
+        char need[64];
+        snprintf(need, sizeof(need), "%zu", w.total);
+        return fail(ILQR_E_WORKSPACE, "problem needs %s bytes of workspace, more than ILQR_STATIC_WORKSPACE_BYTES", need);
+    }
+    void* ws = nullptr;
+    rc = static_workspace(&ws);
+    if (rc) return rc;
+    ilqr_problem q = *p;
+    q.flags |= ILQR_FLAG_SINGLE_STREAM;       // no internal streams, events or host threads
+    hipStream_t s = (hipStream_t)stream;
+    return dispatch(q.model_id, [&](auto M) {
+        using Mt = decltype(M);
+        return run_pipeline<Mt>(&q, x0, u, x, out, (char*)ws, w, s);
     });
 }
 

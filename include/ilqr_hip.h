@@ -144,6 +144,19 @@ size_t ilqr_workspace_bytes(const ilqr_problem *p);
 int ilqr_solve_batch(const ilqr_problem *p, const double *x0, double *u, double *x, const ilqr_outputs *out,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* No counterpart in the reference.  ilqr_solve_batch for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same solve with the workspace in
+ * a device array that is part of the library, ILQR_STATIC_WORKSPACE_BYTES per GPU, held from the first call on
+ * that GPU until the process ends.  The call allocates nothing: no hipMalloc / hipFree, no streams, events or
+ * host threads (it runs on `stream` alone, as with ILQR_FLAG_SINGLE_STREAM; ILQR_FLAG_TIMING is refused).  A
+ * problem whose ilqr_workspace_bytes() exceeds ILQR_STATIC_WORKSPACE_BYTES is refused with ILQR_E_WORKSPACE
+ * (CarModel N = 40: up to about 2 900 trajectories per call).  Results are those of ilqr_solve_batch, bit for bit.
+ * All calls on one GPU share the one array: calls that overlap on the same GPU (two host threads, two streams)
+ * race and must be serialised by the caller. */
+#define ILQR_STATIC_WORKSPACE_BYTES (32u << 20)
+int ilqr_solve_batch_static(const ilqr_problem *p, const double *x0, double *u, double *x, const ilqr_outputs *out,
+                            void *stream);
+
 /* Model.rollout + Model.cost_trj (control/models/model.py:15-20, :31-37 and
  * the plants' cost_trj overrides): x [N][nx][stride] out, J [B] out. */
 int ilqr_rollout_cost(const ilqr_problem *p, const double *x0, const double *u, double *x, double *J, void *stream);
