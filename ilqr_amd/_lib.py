@@ -24,7 +24,7 @@ PHASES = ("init", "backward", "forward1", "backtrack", "commit", "export")
 
 EXPORTS = ("ilqr_model_info", "ilqr_workspace_bytes", "ilqr_solve_batch", "ilqr_rollout_cost",
            "ilqr_model_eval", "ilqr_mpc_advance", "ilqr_last_timing", "ilqr_last_error", "ilqr_version",
-           "ilqr_solve_batch_static")
+           "ilqr_solve_batch_static", "ilqr_eigvals_negative")
 STATIC_WORKSPACE_BYTES = 32 << 20
 
 _dp = C.c_void_p  # device pointers travel as plain addresses
@@ -70,6 +70,8 @@ def lib(path=None):
     L.ilqr_solve_batch.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, C.POINTER(Outputs), _dp, C.c_size_t, _dp]
     L.ilqr_solve_batch_static.restype = C.c_int
     L.ilqr_solve_batch_static.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, C.POINTER(Outputs), _dp]
+    L.ilqr_eigvals_negative.restype = C.c_int
+    L.ilqr_eigvals_negative.argtypes = [C.c_int32, _dp, C.c_int64, C.c_int64, _dp, _dp]
     L.ilqr_rollout_cost.restype = C.c_int
     L.ilqr_rollout_cost.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, _dp, _dp]
     L.ilqr_model_eval.restype = C.c_int

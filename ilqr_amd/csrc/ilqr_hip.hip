@@ -15,6 +15,7 @@
 
 #define ILQR_MAIN_TU
 #include "pipeline_host.hpp"
+#include "eig_device.hpp"
 
 using namespace ilqr;
 
@@ -123,6 +124,21 @@ __global__ __launch_bounds__(WG) void mpc_advance_kernel(Dev a, double* __restri
     for (int i = 0; i < nx; ++i) x0[(long)i * st + b] = xn[i];
     for (int k = 0; k < S - 1; ++k)
         for (int i = 0; i < m; ++i) u[(long)(k * m + i) * st + b] = u[(long)((k + 1) * m + i) * st + b];
+}
+
+// np.any(np.linalg.eigvals(Q) < 0) for one w x w matrix per lane: Q is row-major, entry e of matrix b at Q[e * stride + b]
+template <int W>
+__global__ __launch_bounds__(WG) void eig_negative_kernel(const double* __restrict__ Q, long B, long stride,
+                                                          int32_t* __restrict__ verdict)
+{
+    __shared__ double lds[(W * W + 2 * W) * WG];
+    const long b = (long)blockIdx.x * WG + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const eig::Lane<W, WG> m{lds + lane, lds + W * W * WG + lane};
+    for (int i = 0; i < W; ++i)
+        for (int j = 0; j < W; ++j) m.A(i + 1, j + 1) = Q[(long)(i * W + j) * stride + b];
+    verdict[b] = m.has_negative();
 }
 
 // ---------------------------------------------------------------- host side
@@ -445,6 +461,23 @@ int ilqr_solve_batch_static(const ilqr_problem* p, const double* x0, double* u, 
         using Mt = decltype(M);
         return run_pipeline<Mt>(&q, x0, u, x, out, (char*)ws, w, s);
     });
+}
+
+int ilqr_eigvals_negative(int32_t w, const double* Q, int64_t B, int64_t stride, int32_t* verdict, void* stream)
+{
+    if (!Q || !verdict) return fail(ILQR_E_BADARG, "Q and verdict must be non-NULL");
+    if (B < 1 || stride < B) return fail(ILQR_E_BADARG, "B must be >= 1 and stride >= B");
+    dim3 grid((unsigned)((B + WG - 1) / WG)), block(WG);
+    hipStream_t s = (hipStream_t)stream;
+    switch (w) {
+#define ILQR_EIG_CASE(W_) case W_: hipLaunchKernelGGL(eig_negative_kernel<W_>, grid, block, 0, s, Q, (long)B, (long)stride, verdict); break;
+    ILQR_EIG_CASE(2) ILQR_EIG_CASE(3) ILQR_EIG_CASE(4) ILQR_EIG_CASE(5) ILQR_EIG_CASE(6) ILQR_EIG_CASE(7) ILQR_EIG_CASE(8)
+    ILQR_EIG_CASE(16)
+#undef ILQR_EIG_CASE
+    default: return fail(ILQR_E_BADARG, "ilqr_eigvals_negative is built for orders 2..8 and 16");
+    }
+    HIP_TRY(hipGetLastError());
+    return ILQR_OK;
 }
 
 int ilqr_rollout_cost(const ilqr_problem* p, const double* x0, const double* u, double* x, double* J, void* stream)

@@ -173,6 +173,17 @@ int ilqr_model_eval(const ilqr_problem *p, const double *xs, const double *us, d
                     double *l_x, double *l_u, double *l_xx, double *l_ux, double *l_uu, double *f_x, double *f_u,
                     double *V_x, double *V_xx, void *stream);
 
+/* `np.any(np.linalg.eigvals(Q) < 0)`, the test that drives the regularisation loop of control/iLQRController.py:110,
+ * for B general (not symmetrised) w x w matrices at once, decided like NumPy decides it: from the eigenvalues of
+ * LAPACK's DGEEV (balancing, Householder reduction to Hessenberg form, implicit double-shift QR), computed in
+ * LAPACK's and OpenBLAS' order of operations.  This is the test the solve kernels apply wherever a cheaper, certified
+ * bound does not settle the sign.
+ *   Q [w*w][stride] in, row-major entries: entry (i, j) of matrix b at Q[(i * w + j) * stride + b]
+ *   verdict [B] out: 1 = some eigenvalue compares below zero (complex ones by real part, then imaginary part),
+ *                    0 = none, -1 = NumPy raises LinAlgError (an entry is not finite, or no convergence)
+ * Built for w = 2..8 and 16. */
+int ilqr_eigvals_negative(int32_t w, const double *Q, int64_t B, int64_t stride, int32_t *verdict, void *stream);
+
 /* Receding-horizon helper (control/QuadrotorControllers.py:72-76, :185-188;
  * control/AcrobotControllers.py:60-63): x0 <- discrete_dynamics(x0, u[0]) and
  * u[:-1] <- u[1:] (last row kept), in place, for B trajectories. */
