@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1 << 20, help="trajectories per GPU")
     ap.add_argument("--horizon", type=int, default=40, help="knot points N (40 = the headline workload)")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 20, help="trajectories timed on the host cores (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 17, help="trajectories timed on the host cores (0 = skip)")
     ap.add_argument("--check", type=int, default=2048, help="trajectories checked against the CPU checker (0 = skip)")
     a = ap.parse_args()
 

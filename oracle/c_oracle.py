@@ -67,6 +67,10 @@ def lib(path=None):
         L.ilqr_oracle_eval.argtypes = [C.c_int] + [dp] * 15
         L.ilqr_oracle_has_negative_eig.restype = C.c_int
         L.ilqr_oracle_has_negative_eig.argtypes = [dp, C.c_int, dp]
+        L.ilqr_oracle_has_negative_eig_lapack.restype = C.c_int
+        L.ilqr_oracle_has_negative_eig_lapack.argtypes = [dp, C.c_int, dp]
+        L.ilqr_oracle_set_psd_rule.restype = None
+        L.ilqr_oracle_set_psd_rule.argtypes = [C.c_int]
         L.ilqr_oracle_has_negative_eig_ldl.restype = C.c_int
         L.ilqr_oracle_has_negative_eig_ldl.argtypes = [dp, C.c_int, dp]
         L.ilqr_oracle_unit_qterms.restype = None
@@ -92,8 +96,10 @@ def info_size():
     return INFO_DTYPE.itemsize
 
 
-def solve_batch(model, par, N, max_iter, max_ls, d_tol, x0, u, nthreads=0, library=None):
-    """x0[B,nx], u[B,N-1,nu] (not modified) -> dict(x[B,N,nx], u[B,N-1,nu], info structured array)."""
+def solve_batch(model, par, N, max_iter, max_ls, d_tol, x0, u, nthreads=0, library=None, rule="lapack"):
+    """x0[B,nx], u[B,N-1,nu] (not modified) -> dict(x[B,N,nx], u[B,N-1,nu], info structured array).
+    rule: how `np.any(np.linalg.eigvals(Q) < 0)` is decided -- "lapack" (DGEEV restated: the reference's own verdicts)
+    or "ldl" (the LDL' rule of the HIP kernels: the kernels' algorithm on the CPU)."""
     mid = MODEL_IDS[model] if isinstance(model, str) else model
     nx, nu, ndx, npar = dims(mid, library)
     par = np.ascontiguousarray(par, dtype=np.float64)
@@ -105,8 +111,10 @@ def solve_batch(model, par, N, max_iter, max_ls, d_tol, x0, u, nthreads=0, libra
     info = np.zeros(B, dtype=INFO_DTYPE)
     if nthreads <= 0:
         nthreads = len(os.sched_getaffinity(0))
+    lib(library).ilqr_oracle_set_psd_rule(dict(lapack=0, ldl=1)[rule])
     rc = lib(library).ilqr_oracle_solve_batch(mid, _p(par), N, max_iter, max_ls, float(d_tol), B, _p(x0), _p(u), _p(x),
                                        info.ctypes.data_as(C.c_void_p), nthreads)
+    lib(library).ilqr_oracle_set_psd_rule(0)
     assert rc == 0
     return dict(x=x, u=u, info=info)
 
@@ -131,7 +139,7 @@ def has_negative_eig(Q, rule="lapack"):
     """np.any(np.linalg.eigvals(Q) < 0) by the checker: LAPACK restated (default) or the older LDL^T rule."""
     Q = np.ascontiguousarray(Q, dtype=np.float64)
     W = np.zeros_like(Q)
-    f = lib().ilqr_oracle_has_negative_eig if rule == "lapack" else lib().ilqr_oracle_has_negative_eig_ldl
+    f = lib().ilqr_oracle_has_negative_eig_lapack if rule == "lapack" else lib().ilqr_oracle_has_negative_eig_ldl
     return f(_p(Q), Q.shape[0], _p(W))
 
 

@@ -129,7 +129,7 @@ int ilqr_oracle_has_negative_eig_ldl(const double *Q, int w, double *W)
  * w x w matrix Q, compared with zero the way NumPy compares (complex numbers order by real part, then imaginary).
  * Returns 1 = some eigenvalue is negative, 0 = none, -1 = Q not finite or the QR iteration did not converge
  * (NumPy raises LinAlgError in both cases). `W` is scratch of w*w doubles. */
-int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W)
+int ilqr_oracle_has_negative_eig_lapack(const double *Q, int w, double *W)
 {
     double wr[EIG_MAXN], wi[EIG_MAXN];
     for (int i = 0; i < w; ++i)
@@ -141,6 +141,16 @@ int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W)
     int neg = 0;
     for (int i = 0; i < w; ++i) neg = neg || (wr[i] < 0.0) || (wr[i] == 0.0 && wi[i] < 0.0);
     return neg;
+}
+
+/* Which rule the solver applies: 0 (default) = LAPACK restated, the reference's own; 1 = the LDL^T rule, which is what
+ * the HIP kernels apply -- selecting it makes this checker the kernels' algorithm on the CPU, for comparing the two
+ * statistically on ill-conditioned solves, where the two rules part and no trajectory is reproducible one by one. */
+static int g_psd_rule = 0;
+void ilqr_oracle_set_psd_rule(int rule) { g_psd_rule = rule; }
+int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W)
+{
+    return g_psd_rule == 1 ? ilqr_oracle_has_negative_eig_ldl(Q, w, W) : ilqr_oracle_has_negative_eig_lapack(Q, w, W);
 }
 
 /* np.linalg.inv for m <= ILQR_MAX_NU: Gauss-Jordan with partial pivoting.

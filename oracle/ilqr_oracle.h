@@ -62,7 +62,9 @@ int ilqr_oracle_solve(const ilqr_oracle_model *M, const double *par, int N, int 
 int ilqr_oracle_solve_batch(int model_id, const double *par, int N, int max_iter, int max_ls, double d_tol, long B,
                             const double *x0, double *u, double *x, ilqr_oracle_info *info, int nthreads);
 const ilqr_oracle_model *ilqr_oracle_get_model(int model_id);
-int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W);      /* LAPACK restated */
+int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W);      /* the selected rule */
+int ilqr_oracle_has_negative_eig_lapack(const double *Q, int w, double *W); /* LAPACK restated (default) */
+void ilqr_oracle_set_psd_rule(int rule);                                  /* 0 LAPACK restated, 1 LDL^T */
 int ilqr_oracle_has_negative_eig_ldl(const double *Q, int w, double *W);  /* the LDL^T rule, for scoring */
 void ilqr_oracle_model_dims(int model_id, int *nx, int *nu, int *ndx, int *npar);
 /* Diagnostics: copies the histogram of regularisation rounds per backward stage into out64 (if not NULL),

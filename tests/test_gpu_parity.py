@@ -379,8 +379,10 @@ def test_parts_on_internal_streams_do_not_change_results(torch_gpu, oracle):
 def test_ill_conditioned_regime_matches_checker_statistically(torch_gpu, oracle, kind):
     """Far from hover most 12-state solves are ill conditioned: every stage takes dozens of regularisation
     doublings and individual trajectories are not reproducible (not even by the reference under a 1e-14
-    perturbation).  The population must still behave like the checker's: same exit-reason histogram within a few
-    counts, same amount of regularisation, and mostly identical iteration counts."""
+    perturbation).  The population must still behave like the checker's when the checker applies the kernels' own
+    PSD rule (LDL', `rule="ldl"`): same exit-reason histogram within a few counts, same amount of regularisation,
+    and mostly identical iteration counts.  (With LAPACK's rule the checker regularises longer in this regime:
+    tests/test_population_reference.py holds the numbers for the car.)"""
     rng = np.random.default_rng(21)
     B, N = 128, 100
     c = dict(_cfg(oracle, kind), N=N)
@@ -392,7 +394,7 @@ def test_ill_conditioned_regime_matches_checker_statistically(torch_gpu, oracle,
         x0[:, :4] = q / np.linalg.norm(q, axis=1, keepdims=True)
     u0 = 2.0 * rng.standard_normal((B, N - 1, 4))
     got = _solve(c, x0, u0)
-    ref = oracle.solve_batch(kind, c["par"], N, c["max_iter"], c["max_ls"], c["d_tol"], x0, u0)["info"]
+    ref = oracle.solve_batch(kind, c["par"], N, c["max_iter"], c["max_ls"], c["d_tol"], x0, u0, rule="ldl")["info"]
     assert ref["regu_rounds"].mean() > 1000, "the case is meant to be ill conditioned"
     hg, hr = np.bincount(got["status"], minlength=4), np.bincount(ref["status"], minlength=4)
     assert np.abs(hg - hr).max() <= max(4, B // 20), (hg, hr)
@@ -403,19 +405,23 @@ def test_ill_conditioned_regime_matches_checker_statistically(torch_gpu, oracle,
 
 def test_car_population_statistics_match_checker(torch_gpu, oracle):
     """Headline batch, all trajectories (a quarter of them are ill conditioned and not reproducible one by one):
-    well-conditioned solves agree decision for decision, and the population as a whole exits for the same
-    reasons, regularises as much and iterates as long as the checker's."""
+    well-conditioned solves agree decision for decision with the checker under either PSD rule, and the population
+    as a whole exits for the same reasons, regularises as much and iterates as long as the checker's under the
+    kernels' rule."""
     rng = np.random.default_rng(1234)
     B = 4096
     c = _cfg(oracle, "car")
     x0, u0 = _car_box(rng, B), rng.standard_normal((B, 39, 2)) * 1e-4
     got = _solve(c, x0, u0)
-    ref = oracle.solve_batch("car", c["par"], 40, 50, 20, 1e-3, x0, u0)["info"]
-    calm = ref["max_abs_q"] < 1e5
-    assert calm.mean() > 0.6
-    assert np.array_equal(got["iters"][calm], ref["iters"][calm])
-    assert np.array_equal(got["regu"][calm], ref["regu_rounds"][calm])
-    assert np.array_equal(got["status"][calm], ref["status"][calm])
+    for rule in ("lapack", "ldl"):
+        ref = oracle.solve_batch("car", c["par"], 40, 50, 20, 1e-3, x0, u0, rule=rule)["info"]
+        calm = ref["max_abs_q"] < 1e5
+        assert calm.mean() > 0.6
+        assert np.array_equal(got["iters"][calm], ref["iters"][calm])
+        assert np.array_equal(got["regu"][calm], ref["regu_rounds"][calm])
+        assert np.array_equal(got["status"][calm], ref["status"][calm])
+        same = (got["iters"] == ref["iters"]) & (got["regu"] == ref["regu_rounds"]) & (got["status"] == ref["status"])
+        assert same.mean() > 0.88, (rule, same.mean())
     hg, hr = np.bincount(got["status"], minlength=4), np.bincount(ref["status"], minlength=4)
     assert np.abs(hg - hr).max() <= B // 64, (hg, hr)
     assert 0.9 < got["regu"].mean() / ref["regu_rounds"].mean() < 1.1
@@ -460,7 +466,7 @@ def test_full_size_batch_properties(torch_gpu, oracle):
     assert torch.equal(x2, xs[:, :, idx]) and torch.equal(u2, us[:, :, idx])
     assert torch.equal(o2["iters"], it[idx]) and torch.equal(o2["J"].nan_to_num(), out["J"][idx].nan_to_num())
     # exit statistics against the checker on the first 8192 trajectories
-    ref = oracle.solve_batch("car", c["par"], 40, 50, 20, 1e-3, x0[:8192], u0[:8192])["info"]
+    ref = oracle.solve_batch("car", c["par"], 40, 50, 20, 1e-3, x0[:8192], u0[:8192], rule="ldl")["info"]
     g = np.bincount(st[:8192].cpu().numpy(), minlength=4) / 8192.0
     r = np.bincount(ref["status"], minlength=4) / 8192.0
     assert np.abs(g - r).max() < 0.01, (g, r)

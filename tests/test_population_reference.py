@@ -1,14 +1,23 @@
 """The reference solver itself on 8192 solves of the headline workload (tests/golden/car_population_ref.npz, made by
 tests/golden/make_population.py from the imported reference `iLQR`) against the CPU checker and the HIP path.
 
-Three quarters of these solves are well conditioned (largest |Q| entry the reference met below 1e5): there every
-solve must end like the reference's, one by one.  The rest end through rounding noise of LAPACK's eigenvalues at
-regularisation factors up to 1e16 and are not reproducible one by one (not by the reference itself under a 1e-14
-perturbation); they are held to the reference's statistics within the margins written below."""
+Solves are classed by the largest |Q| entry the reference met: below 1e5 (76 % of the batch) every solve must end like
+the reference's, one by one: same iteration count, exit reason and number of regularisation rounds.  Above that a
+solve amplifies rounding differences (the order of additions in a matrix product is enough), and how often it still
+ends like the reference's falls with the class: about 85 % for 1e5..1e8, 50 % for 1e8..1e12, none beyond 1e16.  That holds
+for the checker with LAPACK's eigenvalue test restated bit for bit (`rule="lapack"`) exactly as for the cheaper LDL'
+rule the kernels apply (`rule="ldl"`): over the whole batch both end like the reference on 90.4-90.5 % of the solves,
+which is the level at which the reference reproduces itself under a 1e-14 perturbation of its inputs (the `stable`
+flag of car_box256.npz).  What the rule does change is the statistics of the hopeless class (beyond 1e16, 6 % of
+the batch): with LAPACK's rule the checker's exit histogram and mean iteration count are the reference's to within
+0.3 % of the batch and 0.5 %; with the LDL' rule more of those solves stop early (max_iter exits 476 instead of 603,
+LinAlgError 34 instead of 2), hence the wider margins below."""
 import numpy as np
 import pytest
 
 from conftest import load_golden
+
+CLASSES = (1e5, 1e8, 1e12, 1e16)
 
 
 def _inputs(n):
@@ -16,31 +25,46 @@ def _inputs(n):
     return bench.car_inputs(n, 1234)
 
 
-def _check(g, iters, status, regu, J, label):
-    calm = g["max_abs_q"] < 1e5
-    assert calm.mean() > 0.7
+def _check(g, iters, status, regu, J, label, faithful_rule):
+    n = len(iters)
+    cls = np.digitize(g["max_abs_q"], CLASSES)
+    same = (iters == g["iters"]) & (status == g["status"]) & (regu == g["regu_rounds"])
+    by_class = [float(same[cls == c].mean()) for c in range(5)]
+    print(label, "ends like the reference: all %.4f, by class of max|Q|" % same.mean(), np.round(by_class, 3),
+          "exits", np.bincount(status, minlength=4), "mean iterations %.3f" % iters.mean())
+    assert (cls == 0).mean() > 0.7
     # well conditioned: identical, one by one
-    assert np.array_equal(iters[calm], g["iters"][calm]), label
-    assert np.array_equal(status[calm], g["status"][calm]), label
-    assert np.array_equal(regu[calm], g["regu_rounds"][calm]), label
+    assert same[cls == 0].all(), label
     very = g["max_abs_q"] < 1e3
     rel = np.abs(J[very] - g["J"][very]) / np.abs(g["J"][very])
     assert rel.max() < 1e-8, (label, rel.max())
-    # the whole population: exit reasons within 2 % of the batch, iteration counts within 8 %
-    n = len(iters)
-    hr, hs = np.bincount(g["status"], minlength=4), np.bincount(status, minlength=4)
-    assert np.abs(hr - hs).max() <= 0.02 * n, (label, hr, hs)
+    # the whole batch, and the first ill-conditioned class
+    assert same.mean() > 0.895, (label, same.mean())
+    assert by_class[1] > 0.8, (label, by_class)
     assert (status == g["status"]).mean() > 0.97, label
     assert (iters == g["iters"]).mean() > 0.93, label
-    assert abs(iters.mean() - g["iters"].mean()) < 0.08 * g["iters"].mean(), label
+    hr, hs = np.bincount(g["status"], minlength=4), np.bincount(status, minlength=4)
+    # regularisation rounds per solve are heavy-tailed (2 % of the solves hold two thirds of them): percentiles
+    p50, p90 = np.percentile(regu, (50, 90))
+    r50, r90 = np.percentile(g["regu_rounds"], (50, 90))
+    assert abs(p50 - r50) <= 1, (label, p50, r50)
+    if faithful_rule:
+        assert np.abs(hr - hs).max() <= 0.005 * n, (label, hr, hs)
+        assert abs(iters.mean() - g["iters"].mean()) < 0.01 * g["iters"].mean(), label
+        assert abs(p90 - r90) <= 0.02 * r90, (label, p90, r90)
+    else:
+        assert np.abs(hr - hs).max() <= 0.02 * n, (label, hr, hs)
+        assert abs(iters.mean() - g["iters"].mean()) < 0.08 * g["iters"].mean(), label
+        assert abs(p90 - r90) <= 0.2 * r90, (label, p90, r90)
 
 
-def test_checker_against_the_reference_population(oracle):
+@pytest.mark.parametrize("rule", ["lapack", "ldl"])
+def test_checker_against_the_reference_population(oracle, rule):
     g = load_golden("car_population_ref")
     n = int(g["n"])
     x0, u0 = _inputs(n)
-    I = oracle.solve_batch("car", oracle.pack_car(2.0, 2.0), 40, 50, 20, 1e-3, x0, u0)["info"]
-    _check(g, I["iters"], I["status"], I["regu_rounds"], I["J_last"], "checker")
+    I = oracle.solve_batch("car", oracle.pack_car(2.0, 2.0), 40, 50, 20, 1e-3, x0, u0, rule=rule)["info"]
+    _check(g, I["iters"], I["status"], I["regu_rounds"], I["J_last"], "checker, rule " + rule, rule == "lapack")
 
 
 @pytest.mark.gpu
@@ -53,4 +77,4 @@ def test_hip_against_the_reference_population():
     x0, u0 = _inputs(n)
     r = BatchSolver(0, [2.0, 2.0], 40, 50, 20, 1e-3).solve(x0, u0)
     cp = lambda t: t.cpu().numpy()
-    _check(g, cp(r.iters), cp(r.status), cp(r.regu_rounds), cp(r.J), "hip")
+    _check(g, cp(r.iters), cp(r.status), cp(r.regu_rounds), cp(r.J), "hip", False)
