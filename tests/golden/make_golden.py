@@ -19,12 +19,14 @@ no reference file is edited.
 
 Each fixture is an .npz of plain arrays: inputs (x0, u_init, parameter block),
 outputs (x, u, J0, per-iteration J / deltaJ / ls_evals / accepted, iters,
-status, regu_rounds, max_abs_q, lam_margin) and a `stable` flag: the same solve
-repeated by the reference with x0 and u_init perturbed in the 14th digit gave
-identical decision counts and trajectories/cost within 1e-8 (`sens` holds the
-observed relative change).  Solves with stable == 0 amplify rounding noise past
-the 1e-8 parity bar inside the reference itself, so they are compared on exit
-status only.
+status, regu_rounds, max_abs_q, lam_margin) and two flags from repeating the same
+solve in the reference with x0 and u_init perturbed in the 14th digit: `dstable`,
+the decision counts (iterations, line-search evaluations and acceptances,
+regularisation rounds, exit) came out identical, and `stable`, in addition
+trajectories and cost moved by at most 1e-8 (`sens` holds the observed relative
+change).  Solves with dstable == 0 are not reproducible by the reference itself and
+are compared on exit status only; for the others the bar on x, u and J follows
+`sens` (tests/helpers.py).
 """
 from __future__ import annotations
 
@@ -234,7 +236,7 @@ def _one(args):
     spec, sp, x0, u0, check_stable = args
     plant = make_plant(spec)
     r = run_reference(plant, sp, x0, u0)
-    stable, sens = 1, 0.0
+    stable, sens, dstable = 1, 0.0, 1
     if check_stable:
         # the same solve with every input perturbed in the 14th digit
         rng = np.random.default_rng(12345)
@@ -244,6 +246,7 @@ def _one(args):
         same = (r["iters"] == r2["iters"] and r["status"] == r2["status"]
                 and np.array_equal(r["ls_evals"], r2["ls_evals"]) and np.array_equal(r["accepted"], r2["accepted"])
                 and r["regu_rounds"] == r2["regu_rounds"])
+        dstable = int(same)
         if r["status"] != 3 and r2["status"] != 3:
             sens = float(np.abs(r["x"] - r2["x"]).max() / max(1e-300, np.abs(r["x"]).max()))
             sens = max(sens, float(np.abs(r["u"] - r2["u"]).max() / max(1e-300, np.abs(r["u"]).max())))
@@ -252,6 +255,7 @@ def _one(args):
         stable = int(same)
     r["sens"] = sens
     r["stable"] = stable
+    r["dstable"] = dstable
     return r
 
 
@@ -264,7 +268,7 @@ def run_cases(name, spec, sp, X0, U0, pool, check_stable=True, extra=None):
         out[k] = np.stack([r[k] for r in res])
     for k in ("J0", "J_last", "dmax", "max_abs_q", "lam_margin", "sens"):
         out[k] = np.array([r[k] for r in res], dtype=np.float64)
-    for k in ("iters", "status", "regu_rounds", "n_eig", "n_complex", "stable"):
+    for k in ("iters", "status", "regu_rounds", "n_eig", "n_complex", "stable", "dstable"):
         out[k] = np.array([r[k] for r in res], dtype=np.int32)
     if extra:
         out.update(extra)
@@ -411,6 +415,49 @@ def gen_quad_quat(pool):
               extra=dict(mpc_steps=6, mpc_traj=2))
 
 
+def gen_baseline_horizons(pool):
+    """The contract's configurations 3, 4 and 5 at their stated horizons from starts the reference solves
+    solves as reproducibly as it can: quadrotors near hover with controls around the hover thrust (m g / 4 = 1.9), the
+    car near the circle it tracks.  At the stated horizons (N = 100, 80, 200) the reference does not reproduce its own
+    decisions under a 1e-14 perturbation even from these starts (thousands of regularisation rounds per solve, |Q| up
+    to 1e308): those fixtures pin exit classes; the same starts at N = 40 / 40 / 60 are reproducible and pin decisions
+    and trajectories."""
+    rng = np.random.default_rng(33)
+    B = 16
+    sp = dict(N=100, max_iter=20, max_ls=10, d_tol=5e-4)
+    X0 = np.zeros((B, 12)); X0[:, 2] = 0.8; X0[:, 3:6] = 0.2 * rng.standard_normal((B, 3))
+    X0[:, :2] = 0.2 * rng.standard_normal((B, 2))
+    run_cases("quad_ea_hover_N100", ea_spec(100), sp, X0, 1.9 + 0.5 * rng.standard_normal((B, 99, 4)), pool)
+    run_cases("quad_ea_hover_N40", ea_spec(40), dict(sp, N=40), X0, 1.9 + 0.5 * rng.standard_normal((B, 39, 4)), pool)
+    spq = dict(sp, N=80)
+    X0 = np.zeros((B, 13)); X0[:, 6] = 0.8; X0[:, 4:6] = 0.2 * rng.standard_normal((B, 2))
+    for b in range(B):
+        X0[b, :4] = euler_zyx_to_quat(0.2 * rng.standard_normal(3))
+    U0 = 1.9 + 0.5 * rng.standard_normal((B, 79, 4))
+    run_cases("quad_quat_hover_N80", quat_spec(80), spq, X0, U0, pool)
+    run_cases("quad_quat_hover_N40", quat_spec(40), dict(sp, N=40), X0, U0[:, :39], pool)
+    # configuration 4: N = 80, 50 steps of receding horizon (QuadrotorControllers.py:173-191): solve, apply u[0]
+    # through the plant's own discrete_dynamics, shift u, re-solve
+    spec = quat_spec(80)
+    plant = make_plant(spec)
+    X0s, U0s = [], []
+    x0 = X0[0].copy(); u = U0[0].copy()
+    for step in range(50):
+        X0s.append(x0.copy()); U0s.append(u.copy())
+        r = run_reference(plant, spq, x0, u)
+        u = r["u"]
+        x0 = np.asarray(plant.discrete_dynamics(x0, u[0])).ravel()
+        u[:-1] = u[1:]
+    run_cases("quad_quat_mpc80", spec, spq, np.array(X0s), np.array(U0s), pool, extra=dict(mpc_steps=50, mpc_traj=1))
+    # configuration 5: Car N = 200 from starts near the circle, heading along it
+    B = 16
+    a = rng.uniform(-np.pi, np.pi, B); rad = 2.0 + 0.2 * rng.standard_normal(B)
+    X0 = np.column_stack([rad * np.cos(a), rad * np.sin(a), a + np.pi / 2 + 0.1 * rng.standard_normal(B),
+                          2.0 + 0.2 * rng.standard_normal(B), 0.05 * rng.standard_normal(B)])
+    run_cases("car_circle_N200", CAR, dict(CAR_SP, N=200), X0, rng.standard_normal((B, 199, 2)) * 1e-4, pool)
+    run_cases("car_circle_N60", CAR, dict(CAR_SP, N=60), X0, rng.standard_normal((B, 59, 2)) * 1e-4, pool)
+
+
 def gen_units(pool):
     """Pure functions of the reference solver on random blocks (iLQRController.py:125-147, model.py:45-53)."""
     from control.iLQRController import iLQR
@@ -475,7 +522,7 @@ def gen_quat_utils(pool):
 
 
 GENS = dict(quat_utils=gen_quat_utils, user_rover=gen_user_rover, car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
-            acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat, units=gen_units)
+            acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat, baseline=gen_baseline_horizons, units=gen_units)
 
 
 def main():

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, load_golden
-from helpers import compare_to_golden, model_key, rel_traj, tolerance
+from helpers import compare_to_golden, min_compared, model_key, rel_traj, tolerance
 
 pytestmark = pytest.mark.gpu
 MID = dict(car=0, acrobot=1, quad_ea=2, quad_quat=3)
@@ -35,8 +35,9 @@ def _solve(g_or_cfg, x0, u0, trace=64, flags=0):
 def test_hip_matches_reference_golden(torch_gpu, name):
     g = load_golden(name)
     r = _solve(g, g["x0"], g["u_init"])
-    compare_to_golden(g, r["x"], r["u"], r["J"], r["iters"], r["status"], r["ls"], r["acc"], r["regu"], J0=r["J0"],
-                      label=name)
+    n = compare_to_golden(g, r["x"], r["u"], r["J"], r["iters"], r["status"], r["ls"], r["acc"], r["regu"], J0=r["J0"],
+                          label=name)
+    assert n >= min_compared(name, g), (name, n)
 
 
 def _car_box(rng, B):
@@ -306,7 +307,7 @@ def test_batch_mpc_follows_reference_closed_loops(torch_gpu):
     for b in range(ntraj):
         ref = q["x0"][b * steps:(b + 1) * steps]
         assert rel_traj(xs[:steps, b], ref).max() < 1e-5, b
-        st = q["stable"][b * steps:(b + 1) * steps] == 1
+        st = q["dstable"][b * steps:(b + 1) * steps] == 1
         assert np.array_equal(its[:, b][st], q["iters"][b * steps:(b + 1) * steps][st]), b
 
 
@@ -471,3 +472,85 @@ def test_full_size_batch_properties(torch_gpu, oracle):
     r = np.bincount(ref["status"], minlength=4) / 8192.0
     assert np.abs(g - r).max() < 0.01, (g, r)
     assert abs(float(it[:8192].double().mean()) - ref["iters"].mean()) < 0.3
+
+
+def test_car_horizon_200_stress_batch(torch_gpu, oracle):
+    """The contract's stress configuration: CarModel N = 200, max_linesearch_iters = 20 (candidates evaluated side by
+    side), 65 536 trajectories.  At this horizon no solve is reproducible one by one, not by the reference itself
+    (fixtures car_N200, car_circle_N200: 0 of 24 decision-stable), so the batch is held to what does not need a second
+    solver -- x is bit for bit the rollout of the returned u, a sub-batch solved alone gives the same bits -- and to
+    the checker's statistics under the kernels' PSD rule on a sample."""
+    import torch
+    from bench import car_inputs
+    from ilqr_amd.batch import BatchSolver
+    B, N = 1 << 16, 200
+    c = _cfg(oracle, "car")
+    x0, u0 = car_inputs(B, 5, N)
+    s = BatchSolver(0, c["par"], N, 50, 20, 1e-3)
+    r = s.solve(x0, u0)
+    st, it = r.status.cpu().numpy(), r.iters.cpu().numpy()
+    assert it.min() >= 1 and it.max() <= 50 and st.min() >= 0 and st.max() <= 3
+    ok = torch.as_tensor(st != 3, device=r.x.device)
+    xr, Jr = s.rollout_cost(x0, r.u)
+    assert torch.equal(xr[ok], r.x[ok])
+    idx = np.arange(0, B, 131)[:384]
+    r2 = s.solve(x0[idx], u0[idx])
+    assert torch.equal(r2.x, r.x[idx]) and torch.equal(r2.u, r.u[idx]) and torch.equal(r2.iters, r.iters[idx])
+    n = 512
+    ref = oracle.solve_batch("car", c["par"], N, 50, 20, 1e-3, x0[:n], u0[:n], rule="ldl")["info"]
+    g = np.bincount(st[:n], minlength=4) / n
+    h = np.bincount(ref["status"], minlength=4) / n
+    assert np.abs(g - h).max() < 0.05, (g, h)
+    assert abs(it[:n].mean() - ref["iters"].mean()) < 0.05 * ref["iters"].mean() + 0.5
+    ratio = r.regu_rounds.cpu().numpy()[:n].mean() / ref["regu_rounds"].mean()
+    assert 0.8 < ratio < 1.25, ratio
+    # The reference's own solves at this horizon (status-class fixtures) run on to max_iter: LAPACK's eigenvalues keep
+    # calling the regularised Q indefinite where the kernels' LDL' rule, which reads pivots below 1e-13 of their terms
+    # as zero, lets the sweep through, after which the expected reduction falls below 1 and the solve stops.  The
+    # checker shows both behaviours (rule="lapack": 7 of 8 and 16 of 16 at max_iter; rule="ldl": none and 2 of 16);
+    # the kernels must show the second.
+    for name in ("car_N200", "car_circle_N200"):
+        q = load_golden(name)
+        rq = _solve(q, q["x0"], q["u_init"])
+        ck = oracle.solve_batch("car", q["par"], N, 50, 20, 1e-3, q["x0"], q["u_init"], rule="ldl")["info"]
+        assert (q["status"] == 2).mean() >= 0.8
+        assert abs((rq["status"] == 2).mean() - (ck["status"] == 2).mean()) <= 0.25, name
+
+
+def test_quaternion_mpc_loop_at_contract_length(torch_gpu, oracle):
+    """The contract's receding-horizon configuration at full length: quaternion quadrotor, N = 80, 50 steps (solve,
+    plant step with u[0], shift u: QuadrotorControllers.py:173-191), 192 loops near hover.  The reference does not
+    reproduce its own decisions at this horizon (fixture quad_quat_mpc80: 0 of 50 steps decision-stable), so the loops are held to
+    properties: every step's plan is bit for bit the rollout of its controls from the state the loop was in, the
+    state the loop moves to is the plant's step from there, loops do not depend on their batch-mates (a subset run
+    alone gives the same bits), and the exit classes of the first solves match the checker's under the kernels'
+    PSD rule."""
+    import torch
+    from ilqr_amd.batch import BatchSolver
+    from ilqr_amd.mpc import BatchMPC
+    rng = np.random.default_rng(44)
+    B, N, steps = 192, 80, 50
+    c = dict(_cfg(oracle, "quad_quat"), N=N)
+    x0, u0 = _inputs("quad_quat", rng, B, N)
+    x0[:, 4:6] = 0.2 * rng.standard_normal((B, 2))
+    s = BatchSolver(3, c["par"], N, c["max_iter"], c["max_ls"], c["d_tol"])
+    log = BatchMPC(s, shift=True).run(x0, u0, steps=steps, keep_plans=True)
+    st = log["status"].cpu().numpy()
+    assert st.shape == (steps, B) and st.min() >= 0 and st.max() <= 3
+    good = torch.as_tensor((st != 3).all(axis=0), device="cuda")        # loops no solve of which ended in a LinAlgError
+    assert int(good.sum()) > B // 4
+    for t in (0, 1, 17, steps - 1):
+        xr, _ = s.rollout_cost(log["x"][t], log["u_plan"][t])
+        ok = torch.as_tensor(st[t] != 3, device="cuda")
+        assert torch.equal(xr[ok], log["x_plan"][t][ok]), t
+        # the next state is the plant's own step with the first control of the plan (= x_plan[1] of a rollout)
+        assert torch.equal(log["x"][t + 1][ok], xr[ok][:, 1]), t
+        assert torch.equal(log["u"][t], log["u_plan"][t][:, 0]), t
+    sub = np.arange(0, B, 7)
+    log2 = BatchMPC(s, shift=True).run(x0[sub], u0[sub], steps=steps)
+    for k in ("x", "u", "iters", "status"):
+        a, b = log[k][:, sub], log2[k]
+        assert torch.equal(a.nan_to_num(), b.nan_to_num()) if a.dtype.is_floating_point else torch.equal(a, b), k
+    ref = oracle.solve_batch("quad_quat", c["par"], N, c["max_iter"], c["max_ls"], c["d_tol"], x0, u0, rule="ldl")["info"]
+    g, h = np.bincount(st[0], minlength=4), np.bincount(ref["status"], minlength=4)
+    assert np.abs(g - h).max() <= max(6, B // 12), (g, h)

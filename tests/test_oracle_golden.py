@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, load_golden
-from helpers import compare_to_golden, model_key
+from helpers import compare_to_golden, min_compared, model_key
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -15,8 +15,10 @@ def test_oracle_matches_reference_golden(oracle, name):
     i = r["info"]
     n = compare_to_golden(g, r["x"], r["u"], i["J_last"], i["iters"], i["status"], i["ls_evals"], i["accepted"],
                           i["regu_rounds"], J0=i["J0"], label=name)
-    if name in ("car_readme", "car_mpc50", "car_dtol", "car_maxiter2", "car_maxls1", "car_N2", "acrobot_N40"):
-        assert n == len(g["iters"])      # every trajectory of these fixtures is compared tightly
+    assert n >= min_compared(name, g), (name, n)
+    if name in ("car_readme", "car_mpc50", "car_dtol", "car_maxiter2", "car_maxls1", "car_N2", "acrobot_N40",
+                "car_circle_N60", "quad_ea_N30", "quad_quat_N30"):
+        assert n == len(g["iters"])      # every trajectory of these fixtures is compared
 
 
 def test_readme_known_answer(oracle):
