@@ -80,6 +80,25 @@ def algorithmic_bytes(nx, n, m, N, B, iters, ls_total, ls_searches):
     return float(io + backward + forward), float(backward), float(forward)
 
 
+GATHERED = ("J", "iters", "status")      # what the ranks exchange at the end of a step: 16 bytes per trajectory
+
+
+def gather_buffers(world, B, out, dev):
+    return {k: torch.empty(world * B, dtype=out[k].dtype, device=dev) for k in GATHERED}
+
+
+def gather_step(dist, gathered, out):
+    """The path's only exchange: every rank's per-trajectory costs, iteration counts and exit codes to every rank."""
+    for k, g in gathered.items():
+        dist.all_gather_into_tensor(g, out[k])
+
+
+def max_over_ranks(dist, seconds, dev):
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,7 +134,7 @@ def main():
     out = solver.alloc_outputs(B)
     gathered = None
     if dist is not None:
-        gathered = {k: torch.empty(world * B, dtype=out[k].dtype, device=dev) for k in ("J", "iters", "status")}
+        gathered = gather_buffers(world, B, out, dev)
 
     def step(ev=None):
         u.copy_(u_init)                       # run_ilqr optimises u in place: restore the initial guess
@@ -125,8 +144,7 @@ def main():
         if ev:
             ev[1].record()
         if dist is not None:
-            for k, g in gathered.items():
-                dist.all_gather_into_tensor(g, out[k])
+            gather_step(dist, gathered, out)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -144,9 +162,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(dist, elapsed, dev)
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
 
     # one more solve with an event pair around every kernel launch (outside the timed region).  It runs the

@@ -41,12 +41,11 @@ struct CarModel {
     static constexpr int NX = 5, NU = 2, NDX = 5, NPAR = 2;
     static constexpr bool UNROLL = true;
     static constexpr bool TEAM_BACKWARD = false;
-    // waves per SIMD the backward kernel is built for: the stage's matrices need ~220 registers per lane, and
-    // asking for 3 or 4 waves makes the compiler spill ~1 KB per lane (measured slower than 2 resident waves)
-#ifndef ILQR_CAR_BW
-#define ILQR_CAR_BW 1
-#endif
-    static constexpr int BACKWARD_WAVES = ILQR_CAR_BW;
+    // second argument of the backward kernel's __launch_bounds__ (minimum waves per SIMD the register allocator must
+    // leave room for).  1 = no cap below the 512 registers of a lane: the kernel comes out at 242 VGPRs, no AGPRs, no
+    // scratch, i.e. two resident waves per SIMD; asking for 3 or 4 makes the compiler spill ~1 KB per lane (measured
+    // slower than 2 resident waves)
+    static constexpr int BACKWARD_WAVES = 1;
     // running trajectories (per part of a batch) below which every line search is evaluated side by side
     static constexpr long TAIL_COUNT = 262144;
     __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)

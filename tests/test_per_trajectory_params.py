@@ -80,8 +80,11 @@ def test_user_plant_with_goals_per_trajectory(torch_gpu):
 def test_references_per_trajectory(torch_gpu, oracle, kind):
     """set_references with one (xref, uref) per trajectory (plants whose parameter block holds the weight
     matrices too): every trajectory of the mixed batch equals, bit for bit, its solve in a batch that shares
-    its references."""
+    its references, and each reference group agrees with the CPU checker solving it with that group's references
+    (decisions identical and x, u within the parity bar on the solves the checker reproduces under a 1e-14
+    perturbation of its inputs)."""
     from ilqr_amd import Acrobot2DModel, QuadrotorEAModel, QuadrotorQuatModel, iLQR
+    from helpers import rel_traj
     from test_gpu_parity import _inputs
     rng = np.random.default_rng(12)
     if kind == "acrobot":
@@ -107,12 +110,31 @@ def test_references_per_trajectory(torch_gpu, oracle, kind):
     which = rng.integers(0, len(refs), B)
     plant = mk()
     plant.set_references(np.stack([refs[g][0] for g in which]), np.stack([refs[g][1] for g in which]))
-    x, u = iLQR(plant, N, **sp).run_ilqr(x0, u0.copy())
+    ctl = iLQR(plant, N, **sp)
+    x, u = ctl.run_ilqr(x0, u0.copy())
+    it_mixed = ctl.info.iters.cpu().numpy()
+    compared = 0
     for g, (xr, ur) in enumerate(refs):
         idx = np.where(which == g)[0]
         shared = mk(); shared.set_references(xr, ur)
         xs, us = iLQR(shared, N, **sp).run_ilqr(x0[idx], u0[idx].copy())
         assert np.array_equal(xs, x[idx], equal_nan=True) and np.array_equal(us, u[idx], equal_nan=True), (kind, g)
+        # the checker with this group's references
+        par = shared._param_block()
+        args = (kind, par, N, sp["max_iter"], sp["max_linesearch_iters"], sp["d_tol"])
+        ref = oracle.solve_batch(*args, x0[idx], u0[idx])
+        sg = np.random.default_rng(5).choice([-1.0, 1.0], size=u0[idx].shape)
+        per = oracle.solve_batch(*args, x0[idx], u0[idx] * (1 + 1e-14 * sg))
+        i, j = ref["info"], per["info"]
+        sens = np.maximum(rel_traj(per["x"], ref["x"]), rel_traj(per["u"], ref["u"]))
+        stable = ((i["iters"] == j["iters"]) & (i["status"] == j["status"]) & (i["regu_rounds"] == j["regu_rounds"])
+                  & (i["status"] != 3) & (sens <= 1e-6))
+        assert np.array_equal(it_mixed[idx][stable], i["iters"][stable]), (kind, g)
+        tol = np.maximum(1e-8, 100 * sens)
+        assert (rel_traj(xs, ref["x"])[stable] <= tol[stable]).all(), (kind, g)
+        assert (rel_traj(us, ref["u"])[stable] <= tol[stable]).all(), (kind, g)
+        compared += int(stable.sum())
+    assert compared >= B // 2, (kind, compared)
     assert not np.array_equal(x[which == 0][0], x[which == 1][0])
 
 

@@ -79,3 +79,40 @@ def test_two_ranks_match_single_process():
             assert a.shape == b.shape
             assert np.array_equal(a, b, equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a, b), (rank, k)
         assert np.array_equal(x_last, ref["x"][:, -1, :].numpy(), equal_nan=True)
+
+
+def _bench_worker(rank, world, port, B, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        dev = torch.device("cpu")
+        out = dict(J=torch.arange(B, dtype=torch.float64) + 1000.0 * rank, iters=torch.arange(B, dtype=torch.int32) + 7 * rank,
+                   status=torch.full((B,), rank, dtype=torch.int32))
+        g = bench.gather_buffers(world, B, out, dev)
+        bench.gather_step(dist, g, out)
+        slowest = bench.max_over_ranks(dist, 1.0 + rank, dev)
+        q.put((rank, {k: v.numpy() for k, v in g.items()}, slowest))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_bench_gather_path_with_two_ranks():
+    """bench.py's own exchange (all-gather of J / iters / status, maximum of the ranks' times) with world size 2."""
+    B, world = 37, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, g, slowest in got:
+        assert slowest == 2.0
+        assert np.array_equal(g["J"], np.concatenate([np.arange(B) + 1000.0 * r for r in range(world)]))
+        assert np.array_equal(g["iters"], np.concatenate([np.arange(B) + 7 * r for r in range(world)]))
+        assert np.array_equal(g["status"], np.repeat(np.arange(world), B))
