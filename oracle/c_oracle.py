@@ -42,11 +42,13 @@ def build_user(header_dir: str, out_dir: str = None) -> str:
     out = os.path.join(out_dir, "libilqr_oracle_user.so")
     src = os.path.join(_HERE, "ilqr_oracle.c")
     hdr = os.path.join(header_dir, "user_gen.h")
-    deps = [src, hdr, os.path.join(_HERE, "eigvals_lapack.h"), os.path.join(_HERE, "ilqr_oracle.h")]
+    plants = os.path.join(_HERE, "plants_ad.cpp")
+    deps = [src, hdr, plants, os.path.join(_HERE, "eigvals_lapack.h"), os.path.join(_HERE, "ilqr_oracle.h"),
+            os.path.join(_HERE, "oracle_models.h")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-fPIC", "-fopenmp",
                                "-Wno-unused-function", "-DORACLE_USER_MODEL", f"-I{header_dir}", f"-I{_HERE}",
-                               "-shared", "-o", out, src, "-lm"])
+                               "-fno-exceptions", "-fno-rtti", "-shared", "-o", out, src, plants, "-lm"])
     return out
 
 

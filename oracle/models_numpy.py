@@ -4,9 +4,9 @@ Nothing in the shipped package may import this module; it exists so that
   (a) the reference solver (imported from /root/reference when it is present)
       can be driven with plant models whose own source files cannot be imported
       in this image (they need pydrake / CasADi, which are not installed), and
-  (b) the plant functions the C checker is compiled with (oracle/gen/*.h,
-      printed by oracle/gen_headers.py) come from the very same arithmetic
-      that the golden vectors were produced with.
+  (b) the golden vectors produced that way can be checked by a second, independent statement of the same plants:
+      the C checker's own (oracle/oracle_models.h for the car, oracle/plants_ad.cpp for the other three, written by
+      hand from the reference and differentiated by forward-mode AD), which has to reproduce them.
 
 Every function cites the reference lines it restates.  The arithmetic is
 written once, over a tiny "math namespace" `m` that is either NumPy or SymPy,

@@ -4,13 +4,15 @@
  *      (control/models/car.py:64-94; derivatives are the closed forms of what
  *      car.py:5-29 obtains symbolically).  Independent of the generated code
  *      the HIP kernels use.
- * Acrobot / quadrotors: continuous dynamics and their Jacobians come from the
- *      generated headers in oracle/gen/ (SymPy differentiation of
- *      oracle/models_numpy.py, which restates acrobot.py:35-72,
- *      Quadrotor_EA.py:57-128, Quadrotor_Quat.py:74-111); RK4 and its
- *      derivative are written here (acrobot.py:76-97 and the same lines in the
- *      quadrotor files).  CasADi differentiates the RK4 graph by AD; the chain
- *      rule below is that derivative in a fixed evaluation order.
+ * Acrobot / quadrotors: continuous dynamics, the attitude Jacobian and the
+ *      quaternion cost are written by hand in oracle/plants_ad.cpp from
+ *      acrobot.py:20-73, Quadrotor_EA.py:47-128, Quadrotor_Quat.py:61-153 and
+ *      maths/casadi_quaternions.py, and differentiated there by forward-mode
+ *      automatic differentiation (dual numbers), independently of the
+ *      SymPy-generated code the HIP kernels use; RK4 and its derivative are
+ *      written here (acrobot.py:76-97 and the same lines in the quadrotor
+ *      files).  CasADi differentiates the RK4 graph by AD; the chain rule
+ *      below is that derivative in a fixed evaluation order.
  */
 #ifndef ORACLE_MODELS_H
 #define ORACLE_MODELS_H
@@ -18,9 +20,17 @@
 #include <string.h>
 
 #include "ilqr_oracle.h"
-#include "gen/acrobot_gen.h"
-#include "gen/quad_ea_gen.h"
-#include "gen/quad_quat_gen.h"
+
+/* oracle/plants_ad.cpp */
+void oracle_acrobot_xdot(const double *x, const double *u, double *f);
+void oracle_acrobot_xdot_jac(const double *x, const double *u, double *f, double *A, double *B);
+void oracle_quad_ea_xdot(const double *x, const double *u, double *f);
+void oracle_quad_ea_xdot_jac(const double *x, const double *u, double *f, double *A, double *B);
+void oracle_quad_quat_xdot(const double *x, const double *u, double *f);
+void oracle_quad_quat_xdot_jac(const double *x, const double *u, double *f, double *A, double *B);
+void oracle_quad_quat_G(const double *x, double *G);
+void oracle_quad_quat_cost(const double *w, const double *x, const double *u, double *c);
+void oracle_quad_quat_cost_derivs(const double *w, const double *x, const double *u, double *lx, double *lu, double *lxx);
 
 void q_terms_default_export(const ilqr_oracle_model *M, const double *par, const double *x, const double *lx,
                             const double *lu, const double *lxx, const double *lux, const double *luu,
@@ -239,8 +249,8 @@ static double quad_form_half(const double *W, const double *e, int n)
     }                                                                                                         \
     DEF_DIFF_SUB(P##_diff, NX)
 
-DEF_QUADRATIC_MODEL(acrobot, 4, 1, acrobot_gen_xdot, acrobot_gen_xdot_jac)
-DEF_QUADRATIC_MODEL(quad_ea, 12, 4, quad_ea_gen_xdot, quad_ea_gen_xdot_jac)
+DEF_QUADRATIC_MODEL(acrobot, 4, 1, oracle_acrobot_xdot, oracle_acrobot_xdot_jac)
+DEF_QUADRATIC_MODEL(quad_ea, 12, 4, oracle_quad_ea_xdot, oracle_quad_ea_xdot_jac)
 
 /* --------------------------- quaternion quadrotor --------------------------- */
 /* parameter block: [dt, qdiag(12), qfdiag(12), rdiag(4), xref(13), uref(4)] */
@@ -253,7 +263,7 @@ DEF_QUADRATIC_MODEL(quad_ea, 12, 4, quad_ea_gen_xdot, quad_ea_gen_xdot_jac)
 
 static void qq_weights(const double *par, int final, double *w)
 {
-    /* generated cost functions take w = [xref(13), uref(4), qdiag(12), rdiag(4)] */
+    /* the cost functions of plants_ad.cpp take w = [xref(13), uref(4), qdiag(12), rdiag(4)] */
     memcpy(w, QQ_XREF(par), 13 * sizeof(double));
     memcpy(w + 13, QQ_UREF(par), 4 * sizeof(double));
     memcpy(w + 17, final ? QQ_QFD(par) : QQ_QD(par), 12 * sizeof(double));
@@ -263,7 +273,7 @@ static void qq_weights(const double *par, int final, double *w)
 static void qq_state_jac(const double *x, double *Gx)
 {
     double G[12];
-    quad_quat_gen_G(x, G);
+    oracle_quad_quat_G(x, G);
     memset(Gx, 0, sizeof(double) * 13 * 12);
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 3; ++j) Gx[i * 12 + j] = G[i * 3 + j];
@@ -271,13 +281,13 @@ static void qq_state_jac(const double *x, double *Gx)
 }
 static void quad_quat_dynamics(const double *par, const double *x, const double *u, double *xn)
 {
-    rk4_step(quad_quat_gen_xdot, 13, QQ_DT(par), x, u, xn);
+    rk4_step(oracle_quad_quat_xdot, 13, QQ_DT(par), x, u, xn);
 }
 static double quad_quat_cost_stage(const double *par, const double *x, const double *u)
 {
     double w[33], c;
     qq_weights(par, 0, w);
-    quad_quat_gen_cost(w, x, u, &c);
+    oracle_quad_quat_cost(w, x, u, &c);
     return c;
 }
 static double quad_quat_cost_final(const double *par, const double *x)
@@ -285,7 +295,7 @@ static double quad_quat_cost_final(const double *par, const double *x)
     /* Quadrotor_Quat.py:153: state part only, weights Qf; u = uref zeroes the action term */
     double w[33], c;
     qq_weights(par, 1, w);
-    quad_quat_gen_cost(w, x, QQ_UREF(par), &c);
+    oracle_quad_quat_cost(w, x, QQ_UREF(par), &c);
     return c;
 }
 /* Quadrotor_Quat.py:231-238, 248-257: l_* in the 13-dim state, f_x = G^T A G, f_u = G^T B */
@@ -294,11 +304,11 @@ static void quad_quat_stage_derivs(const double *par, const double *x, const dou
 {
     double w[33], A[169], B[52], Gx[156], T[156];
     qq_weights(par, 0, w);
-    quad_quat_gen_cost_derivs(w, x, u, lx, lu, lxx);
+    oracle_quad_quat_cost_derivs(w, x, u, lx, lu, lxx);
     memset(lux, 0, sizeof(double) * 4 * 13);
     memset(luu, 0, sizeof(double) * 16);
     for (int i = 0; i < 4; ++i) luu[i * 4 + i] = QQ_RD(par)[i];
-    rk4_jac(quad_quat_gen_xdot_jac, 13, 4, QQ_DT(par), x, u, A, B);
+    rk4_jac(oracle_quad_quat_xdot_jac, 13, 4, QQ_DT(par), x, u, A, B);
     qq_state_jac(x, Gx);
     /* T = G^T A (12x13); fx = T G (12x12) */
     for (int i = 0; i < 12; ++i)
@@ -325,7 +335,7 @@ static void quad_quat_final_derivs(const double *par, const double *x, double *V
 {
     double w[33], vx[13], vu[4], vxx[169], Gx[156], T[156];
     qq_weights(par, 1, w);
-    quad_quat_gen_cost_derivs(w, x, QQ_UREF(par), vx, vu, vxx);
+    oracle_quad_quat_cost_derivs(w, x, QQ_UREF(par), vx, vu, vxx);
     qq_state_jac(x, Gx);
     for (int i = 0; i < 12; ++i)
         for (int j = 0; j < 13; ++j) {
