@@ -7,6 +7,7 @@ lane_plants.hip   the pipeline for the car and for user-defined plants (one traj
 from __future__ import annotations
 
 import os
+import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -30,6 +31,26 @@ def up_to_date(target, deps):
     return all(os.path.getmtime(s) <= t for s in deps)
 
 
+class DeviceCallLeft(RuntimeError):
+    pass
+
+
+def check_everything_inlined(remarks: str, unit: str):
+    """Every device function a kernel uses must have been inlined into it.  A kernel's scratch size is then what
+    its own body spills; with a callee left out of line the size travels from callee to caller through assembler
+    symbols, and builds were seen in which that came out as 0 for a callee with a 676-byte frame (its stack accesses
+    then leave the wave's scratch window: a memory aperture violation on the GPU).  The compiler's resource report
+    names every function it emitted code for: anything that is not a kernel fails the build."""
+    names = re.findall(r"remark: Function Name: (\S+)", remarks)
+    if not names:
+        raise DeviceCallLeft(f"{unit}: no resource report from the compiler (is -Rpass-analysis still passed?)")
+    left = sorted({n for n in names if "kernel" not in n})
+    dyn = re.findall(r"Dynamic Stack: True", remarks)
+    if left or dyn:
+        raise DeviceCallLeft(f"{unit}: device functions left out of line (mark them __forceinline__): {left[:8]}"
+                             + (" ; a kernel has a dynamic stack" if dyn else ""))
+
+
 def build_library(out_so, defines=(), include_dirs=(), hipcc=None):
     """Compile both translation units with the given -D / -I options and link them into out_so."""
     hipcc = hipcc or os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -41,11 +62,18 @@ def build_library(out_so, defines=(), include_dirs=(), hipcc=None):
     for src, extra in UNITS:
         obj = os.path.join(out_dir, f".{tag}.{os.path.splitext(src)[0]}.o")
         objs.append(obj)
-        procs.append(subprocess.Popen([hipcc, *common, *extra, "-c", "-o", obj, os.path.join(CSRC, src)]))
+        procs.append((src, subprocess.Popen([hipcc, *common, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", "-o",
+                                             obj, os.path.join(CSRC, src)], stderr=subprocess.PIPE, text=True)))
     try:
-        for p in procs:
-            if p.wait() != 0:
+        for src, p in procs:
+            _, err = p.communicate()
+            rest = "\n".join(line for line in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in line
+                             and not re.match(r"^\s*(\d+ \||\||\^)|^In file included from", line))
+            if rest.strip():
+                print(rest)
+            if p.returncode != 0:
                 raise subprocess.CalledProcessError(p.returncode, p.args)
+            check_everything_inlined(err, src)
         tmp = os.path.join(out_dir, f".{tag}.so")
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp, *objs])
         os.replace(tmp, out_so)
