@@ -255,13 +255,30 @@ def user_library_dir(key, name, out_root=None):
 def build_user_library(nx, nu, n_par, exprs, name, out_root=None, hipcc=None, force=False):
     """Compile the solver for a traced plant (hipcc, gfx950).  The library lands in
     <out_root>/<name>_<key>/libilqr_user.so (default out_root: ilqr_amd/lib/user), next to the generated
-    user_gen.h, and is reused when present."""
+    user_gen.h and a stamp of the solver sources it was compiled from; it is reused only while that stamp is the
+    current one (a library built from older kernels or an older ilqr_problem / ilqr_outputs layout is rebuilt)."""
     d = user_library_dir(user_key(nx, nu, n_par, exprs), name, out_root)
     so = os.path.join(d, "libilqr_user.so")
-    if os.path.exists(so) and not force:
+    stamp_file = os.path.join(d, "sources.sha256")
+    stamp = solver_sources_stamp()
+    if os.path.exists(so) and not force and os.path.exists(stamp_file) and open(stamp_file).read().strip() == stamp:
         return so
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, "user_gen.h"), "w") as fh:
         fh.write(generate_user_header(nx, nu, n_par, exprs, name))
     from .build import build_library
-    return build_library(so, defines=("ILQR_USER_MODEL", "ILQR_ONLY_USER"), include_dirs=(d,), hipcc=hipcc)
+    build_library(so, defines=("ILQR_USER_MODEL", "ILQR_ONLY_USER"), include_dirs=(d,), hipcc=hipcc)
+    with open(stamp_file, "w") as fh:
+        fh.write(stamp + "\n")
+    return so
+
+
+def solver_sources_stamp():
+    """Hash of everything a solver library is compiled from besides the plant's own header."""
+    from .build import sources
+    h = hashlib.sha256()
+    for path in sorted(sources()):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()

@@ -46,9 +46,12 @@ def build_user(header_dir: str, out_dir: str = None) -> str:
     deps = [src, hdr, plants, os.path.join(_HERE, "eigvals_lapack.h"), os.path.join(_HERE, "ilqr_oracle.h"),
             os.path.join(_HERE, "oracle_models.h")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        obj = os.path.join(out_dir, "plants_ad.o")
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-fno-exceptions", "-fno-rtti",
+                               "-c", "-o", obj, plants])
         subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-fPIC", "-fopenmp",
                                "-Wno-unused-function", "-DORACLE_USER_MODEL", f"-I{header_dir}", f"-I{_HERE}",
-                               "-fno-exceptions", "-fno-rtti", "-shared", "-o", out, src, plants, "-lm"])
+                               "-shared", "-o", out, src, obj, "-lm"])
     return out
 
 
