@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 20, help="trajectories per GPU")
     ap.add_argument("--horizon", type=int, default=40, help="knot points N (40 = the headline workload)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 17, help="trajectories timed on the host cores (0 = skip)")
+    ap.add_argument("--lapack-eigvals", action="store_true",
+                    help="ILQR_FLAG_LAPACK_EIGVALS: every PSD test the way NumPy makes it (not the headline line)")
     ap.add_argument("--check", type=int, default=2048, help="trajectories checked against the CPU checker (0 = skip)")
     a = ap.parse_args()
 
@@ -125,7 +127,9 @@ def main():
     from ilqr_amd.batch import BatchSolver
     B, N, nx, m, n = a.batch, a.horizon, 5, 2, 5
     S = N - 1
-    solver = BatchSolver(0, [2.0, 2.0], N, 50, 20, 1e-3, device=dev)
+    from ilqr_amd import _lib as _flags
+    solver = BatchSolver(0, [2.0, 2.0], N, 50, 20, 1e-3, device=dev,
+                         flags=_flags.FLAG_LAPACK_EIGVALS if a.lapack_eigvals else 0)
     x0_np, u0_np = car_inputs(B, 1234 + rank, N)
     x0 = torch.as_tensor(x0_np).to(dev).t().contiguous()                  # [nx, B]
     u_init = torch.as_tensor(u0_np).to(dev).permute(1, 2, 0).contiguous()  # [S, m, B]

@@ -20,6 +20,7 @@ FLAG_LS_SEQUENTIAL = 2
 FLAG_TIMING = 4
 FLAG_SINGLE_STREAM = 8
 FLAG_PARAMS_PER_TRAJECTORY = 16
+FLAG_LAPACK_EIGVALS = 32
 PHASES = ("init", "backward", "forward1", "backtrack", "commit", "export")
 
 EXPORTS = ("ilqr_model_info", "ilqr_workspace_bytes", "ilqr_solve_batch", "ilqr_rollout_cost",

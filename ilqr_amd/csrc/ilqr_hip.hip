@@ -170,6 +170,8 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
     if (p->stride < p->B) return fail(ILQR_E_BADARG, "stride must be >= B");
     if (!p->params) return fail(ILQR_E_BADARG, "params is NULL");
     if (p->max_iter < 0 || p->max_ls < 0 || p->trace_len < 0) return fail(ILQR_E_BADARG, "negative count");
+    if ((p->flags & ILQR_FLAG_LAPACK_EIGVALS) && d.ndx + d.nu > 8)
+        return fail(ILQR_E_BADARG, "ILQR_FLAG_LAPACK_EIGVALS is built for the plants solved one trajectory per lane");
     if ((p->flags & ILQR_FLAG_LS_SEQUENTIAL) && p->max_ls > 60)
         return fail(ILQR_E_BADARG, "ILQR_FLAG_LS_SEQUENTIAL supports max_ls <= 60");
     return ILQR_OK;

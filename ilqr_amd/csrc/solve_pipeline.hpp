@@ -205,10 +205,12 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_export_kernel(Pipe a)
 }
 
 // ---------------------------------------------------------------- backward
-template <class M, bool PT = false>
+// EXACT: ILQR_FLAG_LAPACK_EIGVALS, every PSD test through the LAPACK path of eig_device.hpp
+template <class M, bool PT = false, bool EXACT = false>
 __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kernel(Pipe a)
 {
-    __shared__ double lds[stage_lds_doubles<M::NDX, M::NU, TermsOf<M>::type::AUX>()];
+    __shared__ double lds[stage_lds_doubles<M::NDX, M::NU, TermsOf<M>::type::AUX>() +
+                          (EXACT ? exact_lds_doubles<M::NDX, M::NU>() : 0)];
     const int s0 = blockIdx.x * PIPE_WG + threadIdx.x;
     const bool live = s0 < a.count;
     const int s = live ? s0 : a.count - 1;      // a lane without a trajectory shadows the last one and stores nothing
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
     int rr = 0, rs = 0;
     const ParCache<M> par = params_of<M, PT>(a, id);
     const RecOut G = live ? RecOut{a.G + (long)s * Rec<M>::RG, a.cap * Rec<M>::RG} : RecOut{a.Gscratch, Rec<M>::RG};
-    const bool ok = backward_pass<M>(par.get(), T, G, S, deltaJ, dmax, rr, rs, maxq, live, lds);     // :49
+    const bool ok = backward_pass<M, EXACT>(par.get(), T, G, S, deltaJ, dmax, rr, rs, maxq, live, lds);     // :49
     if (live) {
         a.iters[id] = it;
         a.maxq[id] = maxq;

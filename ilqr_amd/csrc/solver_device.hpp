@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "eig_device.hpp"
 #include "models.hpp"
 
 namespace ilqr {
@@ -381,6 +382,57 @@ constexpr int scan_lds_doubles() { return REGU_GROUPS * QPack<n, m>::NL + REGU_G
 template <int n, int m, int AUX>
 constexpr int stage_lds_doubles() { return scan_lds_doubles<n, m>() + 64 * (QPack<n, m>::NL + AUX); }
 
+// With ILQR_FLAG_LAPACK_EIGVALS every test is made the way NumPy makes it (eig_device.hpp) on the full matrix, both
+// triangles.  That needs, per wavefront, one matrix and its work space per lane, and the entries above the diagonal
+// of Q(0) of every published trajectory (they live in the source lane's registers otherwise).
+template <int n, int m>
+constexpr int exact_lds_doubles()
+{
+    return ((n + m) * (n + m) + 2 * (n + m)) * 64 + (REGU_GROUPS * QPack<n, m>::NUP + 1) / 2 * 2;
+}
+// the lane's matrix for eig::Lane from the packed lower triangle L and the upper entries U of Qxx and Quu
+// (the Qux block is one block: its mirror image fills the upper right corner, as _full_hessian does, :139-147)
+template <int n, int m>
+__device__ __forceinline__ void fill_full(const eig::Lane<n + m, 64>& E, const double* L, const double* U)
+{
+    using QP = QPack<n, m>;
+    constexpr int w = n + m;
+#pragma unroll
+    for (int i = 0; i < w; ++i)
+#pragma unroll
+        for (int j = 0; j < w; ++j) {
+            double v;
+            if (i >= j) v = L[tri(i, j)];
+            else if (j < n) v = U[upp(n, i, j)];
+            else if (i >= n) v = U[upp(m, i - n, j - n, QP::UUB)];
+            else v = L[tri(j, i)];
+            E.A(i + 1, j + 1) = v;
+        }
+}
+// position in the lower triangle of P of the mirror image of upper entry e of QU
+template <int n, int m>
+__device__ __forceinline__ constexpr int mirror_of_upper(int e)
+{
+    using QP = QPack<n, m>;
+    int k = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j, ++k)
+            if (k == e) return tri(j, i);
+    for (int i = 0; i < m; ++i)
+        for (int j = i + 1; j < m; ++j, ++k)
+            if (k == e) return tri(n + j, n + i);
+    return 0;
+}
+// largest |entry| of a packed lower triangle joined to mq (a NaN entry never wins)
+template <int NL>
+__device__ __forceinline__ double max_abs_packed(const double* L, double mq)
+{
+    double a[4] = {mq, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < NL; ++e) a[e & 3] = fmax(a[e & 3], fabs(L[e]));
+    return fmax(fmax(a[0], a[1]), fmax(a[2], a[3]));
+}
+
 #ifndef ILQR_BUILD_CHUNK
 #define ILQR_BUILD_CHUNK 8
 #endif
@@ -416,7 +468,7 @@ __device__ __forceinline__ void build_regularised(double* L, double coef, const 
 // lane carries a trajectory); `lds` holds stage_lds_doubles() doubles.
 // Returns false on the LinAlgError cases.
 // ------------------------------------------------------------------
-template <class M>
+template <class M, bool EXACT = false>
 __device__ __forceinline__ bool backward_stage(const double* par, double* xu, const double* next, double* Vx, double* V,
                                       double* dk, double* Kk, double& redu, int& regu_rounds, int& regu_stages,
                                       double& maxq, bool alive, double* lds)
@@ -433,6 +485,10 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
     double* const ldsP = lds;                                                   // P of the published trajectories
     int* const srcs = reinterpret_cast<int*>(lds + REGU_GROUPS * NL);           // their lanes
     double* const park = lds + scan_lds_doubles<n, m>() + lane;                 // this lane's park, stride 64
+    // EXACT: the lane's matrix and work space for the LAPACK path, and the published trajectories' upper entries
+    double* const exact0 = lds + stage_lds_doubles<n, m, TermsOf<M>::type::AUX>();
+    const eig::Lane<w, 64> E{exact0 + lane, exact0 + w * w * 64 + lane};
+    double* const ldsQU = exact0 + (w * w + 2 * w) * 64;
     {
         double aux[TR::AUX];
         TR::backward_terms(par, xk, uk, Vx, V, Qx, Qu, QL, QU, aux);
@@ -453,7 +509,14 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
     // ---- round 0 in every lane, in place (Q(0) itself is in the park), then the wavefront scans
     bool need;
     {
-        const int neg = has_negative_eig_packed<w, UF>(QL, maxq);
+        int neg;
+        if constexpr (EXACT) {
+            maxq = max_abs_packed<NL>(QL, maxq);
+            fill_full<n, m>(E, QL, QU);
+            neg = E.has_negative();
+        } else {
+            neg = has_negative_eig_packed<w, UF>(QL, maxq);
+        }
         ok = ok && (neg >= 0);
         need = alive && (neg == 1);
     }
@@ -478,6 +541,10 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
             ILQR_UNROLL
             for (int e = 0; e < NL; ++e) ldsP[rank * NL + e] = PL[e];
             srcs[rank] = lane;
+            if constexpr (EXACT) {
+                ILQR_UNROLL
+                for (int e = 0; e < NUP; ++e) ldsQU[rank * NUP + e] = QU[e];
+            }
         }
         wave_sync();
         int t = 1;
@@ -485,7 +552,17 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
         if (g < nsrc) {
             double L[NL];
             build_regularised<NL>(L, regu_coef(c + 1), ldsP + g * NL, park - lane + srcs[g]);
-            t = has_negative_eig_packed<w, UF>(L, mq);
+            if constexpr (EXACT) {
+                double U[NUP > 0 ? NUP : 1];
+                ILQR_UNROLL
+                for (int e = 0; e < NUP; ++e)
+                    U[e] = __builtin_fma(regu_coef(c + 1), ldsP[g * NL + mirror_of_upper<n, m>(e)], ldsQU[g * NUP + e]);
+                mq = max_abs_packed<NL>(L, mq);
+                fill_full<n, m>(E, L, U);
+                t = E.has_negative();
+            } else {
+                t = has_negative_eig_packed<w, UF>(L, mq);
+            }
         }
         // first passing round of every group, its verdict, and the largest |Q| met up to it
         const unsigned long long passed = __ballot(t != 1);
@@ -549,13 +626,28 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
             TR::regu_p(aux, PL);
             ILQR_UNROLL
             for (int e = 0; e < NL; ++e) ldsP[e] = PL[e];
+            if constexpr (EXACT) {
+                ILQR_UNROLL
+                for (int e = 0; e < NUP; ++e) ldsQU[e] = QU[e];
+            }
         }
         for (int base = REGU_BASE + 1;; base += 64) {
             wave_sync();     // P and Q(0) are read from LDS again on every trip, not held in registers across the loop
             double L[NL];
             build_regularised<NL>(L, regu_coef(base + lane), ldsP, park - lane + src);
             double mq = 0.0;
-            const int t = has_negative_eig_packed<w, UF>(L, mq);
+            int t;
+            if constexpr (EXACT) {
+                double U[NUP > 0 ? NUP : 1];
+                ILQR_UNROLL
+                for (int e = 0; e < NUP; ++e)
+                    U[e] = __builtin_fma(regu_coef(base + lane), ldsP[mirror_of_upper<n, m>(e)], ldsQU[e]);
+                mq = max_abs_packed<NL>(L, mq);
+                fill_full<n, m>(E, L, U);
+                t = E.has_negative();
+            } else {
+                t = has_negative_eig_packed<w, UF>(L, mq);
+            }
             const unsigned long long stops = __ballot(t != 1);
             if (stops) {
                 const int win = __ffsll((long long)stops) - 1;
@@ -778,7 +870,7 @@ struct Dest {
 // on.  Reads the T records, writes the G records; returns deltaJ and max_k |d_k|_2 (with NumPy's NaN propagation, as
 // np.max(np.linalg.norm(d, axis=1)) has).  Returns false on LinAlgError.
 // ------------------------------------------------------------------
-template <class M>
+template <class M, bool EXACT = false>
 __device__ __forceinline__ bool backward_pass(const double* par, const RecIn& T, const RecOut& G, int S, double& deltaJ,
                                      double& dmax, int& regu_rounds, int& regu_stages, double& maxq, bool active,
                                      double* lds)
@@ -799,7 +891,7 @@ __device__ __forceinline__ bool backward_pass(const double* par, const RecIn& T,
     for (int k = S - 1; k >= 0; --k) {
         const bool alive = active && ok;
         // (the stage leaves the record of stage k - 1 in xu; the last one loads its own again)
-        const bool good = backward_stage<M>(par, xu, T.p + (long)(k > 0 ? k - 1 : 0) * T.ss, Vx, V, dk, Kk, redu,
+        const bool good = backward_stage<M, EXACT>(par, xu, T.p + (long)(k > 0 ? k - 1 : 0) * T.ss, Vx, V, dk, Kk, redu,
                                             regu_rounds, regu_stages, maxq, alive, lds);
         ok = ok && good;
         // stored by every lane, whatever its state (a lane without a trajectory is given a scratch record by

@@ -82,7 +82,17 @@ enum {
      * user-defined plants) takes it strided like every other array of the call, parameter i of trajectory b at
      * params[i * stride + b]; the plants with larger blocks (acrobot, quadrotors) take the blocks one after the
      * other, trajectory b's block at params + b * npar, so that its matrices stay contiguous. */
-    ILQR_FLAG_PARAMS_PER_TRAJECTORY = 16
+    ILQR_FLAG_PARAMS_PER_TRAJECTORY = 16,
+    /* `np.any(np.linalg.eigvals(Q) < 0)` (control/iLQRController.py:110) decided in every backward stage and every
+     * regularisation round the way NumPy decides it -- the eigenvalues of LAPACK's DGEEV on the general matrix, both
+     * triangles (ilqr_eigvals_negative) -- instead of the default unpivoted LDL' of the lower triangle.  The two agree
+     * wherever the smallest eigenvalue is resolved, i.e. on every solve the reference itself reproduces under a
+     * 1e-14 perturbation of its inputs.  They part where Q has been regularised to ~1e16 times its own size or has
+     * lost its symmetry (long horizons: CarModel N = 200; the quadrotors far from hover): there LAPACK keeps calling Q
+     * indefinite for tens of rounds more, and this flag reproduces the reference's exit classes and iteration
+     * counts as a population.  An eigenvalue computation per test instead of a factorisation: about 30x slower on the
+     * headline batch.  Car, acrobot and user-defined plants (one trajectory per lane); the 12-state plants refuse it. */
+    ILQR_FLAG_LAPACK_EIGVALS = 32
 };
 
 /* Kernel phases of ilqr_solve_batch, for ilqr_timing. */

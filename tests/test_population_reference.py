@@ -78,3 +78,19 @@ def test_hip_against_the_reference_population():
     r = BatchSolver(0, [2.0, 2.0], 40, 50, 20, 1e-3).solve(x0, u0)
     cp = lambda t: t.cpu().numpy()
     _check(g, cp(r.iters), cp(r.status), cp(r.regu_rounds), cp(r.J), "hip", False)
+
+
+@pytest.mark.gpu
+def test_hip_with_lapacks_rule_against_the_reference_population():
+    """ILQR_FLAG_LAPACK_EIGVALS: every PSD test in the kernels through the LAPACK path.  The population then has the
+    reference's exit histogram and iteration counts to the margins the bit-exact checker reaches."""
+    import torch
+    assert torch.cuda.is_available(), "this test needs a GPU"
+    from ilqr_amd import _lib
+    from ilqr_amd.batch import BatchSolver
+    g = load_golden("car_population_ref")
+    n = int(g["n"])
+    x0, u0 = _inputs(n)
+    r = BatchSolver(0, [2.0, 2.0], 40, 50, 20, 1e-3, flags=_lib.FLAG_LAPACK_EIGVALS).solve(x0, u0)
+    cp = lambda t: t.cpu().numpy()
+    _check(g, cp(r.iters), cp(r.status), cp(r.regu_rounds), cp(r.J), "hip, LAPACK's rule", True)
