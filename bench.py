@@ -67,17 +67,25 @@ def algorithmic_flops(n, m, S, ops, iters, regu_rounds, regu_stages, ls_total, B
     return float(init), float(backward), float(forward)
 
 
-def algorithmic_bytes(nx, n, m, N, B, iters, ls_total, ls_searches):
-    """Bytes a solve has to move when every pass streams its operands once (8-byte doubles, no padding):
-    the caller's x0, u in and x, u, J out; per backward pass x, u in and d, K out; per line-search
-    evaluation x, u, d, K in; per search the accepted x, u out.  Returns (solve total, backward, line search)."""
+def algorithmic_bytes(nx, m, N, B):
+    """Bytes a batch has to move whatever the implementation: the caller's x0 and u in, x, u and J plus 12 bytes of
+    counters out (8-byte doubles, no padding).  CarModel N = 40: 2 908 bytes per solve.  Gains and intermediate
+    trajectories are not counted: a solve that kept them on chip would not move them."""
+    S = N - 1
+    return float(B * (8 * (nx + S * m) + 8 * (N * nx + S * m + 1) + 12))
+
+
+def streamed_bytes(nx, n, m, N, B, iters, ls_total, ls_searches):
+    """Model of what THIS implementation moves: one kernel per phase of an iteration, every pass streaming its
+    operands through HBM once.  The caller's arrays as above; per backward pass x, u in and d, K out; per
+    line-search evaluation x, u, d, K in; per search the accepted x, u out.  Returns (solve total, backward,
+    line search)."""
     S = N - 1
     traj = N * nx + S * m
     gains = S * (m + m * n)
-    io = B * (8 * (nx + S * m) + 8 * (traj + 1) + 12)
     backward = iters * 8 * (traj + gains)
     forward = ls_total * 8 * (traj + gains) + ls_searches * 8 * traj
-    return float(io + backward + forward), float(backward), float(forward)
+    return float(algorithmic_bytes(nx, m, N, B) + backward + forward), float(backward), float(forward)
 
 
 GATHERED = ("J", "iters", "status")      # what the ranks exchange at the end of a step: 16 bytes per trajectory
@@ -192,17 +200,20 @@ def main():
         # in the backward kernel (deltaJ < 1 or a LinAlgError)
         searches = iters - status[1] - status[3]
         f_init, f_bwd, f_fwd = algorithmic_flops(n, m, S, ops, iters, regu_rounds, regu_stages, ls_total, B)
-        b_all, b_bwd, b_fwd = algorithmic_bytes(nx, n, m, N, B, iters, ls_total, searches)
+        b_alg = algorithmic_bytes(nx, m, N, B)
+        b_all, b_bwd, b_fwd = streamed_bytes(nx, n, m, N, B, iters, ls_total, searches)
         flops = f_init + f_bwd + f_fwd
         tfl = flops / (kernel_ms * 1e-3) / 1e12
-        gbs = b_all / (kernel_ms * 1e-3) / 1e9
+        gbs = b_alg / (kernel_ms * 1e-3) / 1e9
         bw_ms, bw_launches = phases["backward"]
         ls_ms = phases["forward1"][0] + phases["backtrack"][0] + phases["commit"][0]
         bw_tfl = f_bwd / (bw_ms * 1e-3) / 1e12
         ls_gbs = b_fwd / (ls_ms * 1e-3) / 1e9
+        # HBM bytes from the hardware counters cannot be read from inside the run: they come from the last
+        # rocprofv3 --pmc passes over this same command (tools/collect_traffic.py), kept in profiles/
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and B == 1 << 20 and N == 40 and not a.lapack_eigvals:
             try:
                 traffic = json.load(open(tpath))
             except Exception:
@@ -224,6 +235,8 @@ def main():
                          "achieved": bw_tfl, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": bw_tfl / FP64_PEAK_TFLOPS,
                          "traffic": (traffic or {}).get("backward_hbm_bytes_per_solve"),
+                         "traffic_source": "profiles/traffic_latest.json: FETCH_SIZE and WRITE_SIZE of separate rocprofv3 --pmc "
+                                           "passes over this command (tools/collect_traffic.py), not collected in this run",
                          "timing": "HIP events around each launch, one extra solve of the same batch on a single stream "
                                    "(ILQR_FLAG_TIMING | ILQR_FLAG_SINGLE_STREAM); the timed region overlaps 3 parts",
                          "launches_per_solve": bw_launches, "kernel_ms_per_solve": bw_ms,
@@ -232,11 +245,17 @@ def main():
                                          "achieved": ls_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": ls_gbs / HBM_PEAK_GBS,
                                          "traffic": (traffic or {}).get("line_search_hbm_bytes_per_solve"),
-                                         "kernel_ms_per_solve": ls_ms, "algorithmic_bytes_per_solve": b_fwd},
+                                         "achieved_is": "streamed-bytes model of this implementation (every pass "
+                                                        "through HBM once) / kernel time; the algorithmic bytes of a "
+                                                        "solve are the caller's arrays only, see solve",
+                                         "kernel_ms_per_solve": ls_ms, "streamed_bytes_model": b_fwd},
                          "solve": {"kernel_ms": kernel_ms, "tflops": tfl, "frac_fp64_peak": tfl / FP64_PEAK_TFLOPS,
-                                   "gbs": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS, "algorithmic_flops": flops,
-                                   "algorithmic_bytes": b_all,
-                                   "traffic": (traffic or {}).get("solve_hbm_bytes")},
+                                   "algorithmic_flops": flops,
+                                   "algorithmic_bytes": b_alg, "algorithmic_bytes_per_solve": b_alg / B,
+                                   "gbs": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS,
+                                   "streamed_bytes_model": b_all, "streamed_gbs": b_all / (kernel_ms * 1e-3) / 1e9,
+                                   "traffic": (traffic or {}).get("solve_hbm_bytes"),
+                                   "traffic_over_algorithmic": ((traffic or {}).get("solve_hbm_bytes") or 0) / b_alg or None},
                          "phase_ms": {k: v[0] for k, v in phases.items() if k != "iterations"},
                          "phase_launches": {k: v[1] for k, v in phases.items() if k != "iterations"}},
         }

@@ -34,12 +34,12 @@ _dp = C.c_void_p  # device pointers travel as plain addresses
 class Problem(C.Structure):
     _fields_ = [("model_id", C.c_int32), ("N", C.c_int32), ("max_iter", C.c_int32), ("max_ls", C.c_int32),
                 ("d_tol", C.c_double), ("B", C.c_int64), ("stride", C.c_int64), ("params", _dp),
-                ("trace_len", C.c_int32), ("flags", C.c_int32)]
+                ("trace_len", C.c_int32), ("flags", C.c_int32), ("cost_N", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class Outputs(C.Structure):
     _fields_ = [(k, _dp) for k in ("J0", "J", "dmax", "max_abs_q", "iters", "status", "regu_rounds", "ls_total",
-                                   "regu_stages", "ls_evals", "accepted", "J_trace", "deltaJ_trace")]
+                                   "regu_stages", "ls_evals", "accepted", "J_trace", "deltaJ_trace", "last_search")]
 
 
 class Timing(C.Structure):

@@ -42,12 +42,14 @@ class BatchResult:
     regu_rounds: torch.Tensor
     ls_total: torch.Tensor
     regu_stages: torch.Tensor = None
+    last_search: torch.Tensor = None      # 0 no line search in this call, 1 the last one accepted, 2 it was abandoned
     traces: dict = field(default_factory=dict)
 
 
 class BatchSolver:
     def __init__(self, model_id: int, params, N: int, max_iter: int, max_linesearch_iters: int = 20,
-                 d_tol: float = 1e-3, device="cuda:0", trace_len: int = 0, flags: int = 0, library=None):
+                 d_tol: float = 1e-3, device="cuda:0", trace_len: int = 0, flags: int = 0, library=None,
+                 cost_N: int = 0):
         # library: path of a solver library built for a user-defined plant (ilqr_amd.models.user); default built-ins
         self.lib = _lib.lib(library)
         self.model_id = int(model_id)
@@ -60,6 +62,8 @@ class BatchSolver:
             raise RuntimeError("BatchSolver needs a GPU device (there is no CPU path)")
         self.trace_len = int(trace_len)
         self.flags = int(flags)
+        # knot points the trajectory cost sums over (0 = N): ilqr_problem::cost_N
+        self.cost_N = int(cost_N)
         self.set_params(params)
         self._ws = None
 
@@ -104,7 +108,7 @@ class BatchSolver:
             par = self._params_dev
             flags |= _lib.FLAG_PARAMS_PER_TRAJECTORY
         return _lib.Problem(self.model_id, self.N, self.max_iter, self.max_ls, self.d_tol, B, stride,
-                            C.c_void_p(par.data_ptr()), self.trace_len, flags)
+                            C.c_void_p(par.data_ptr()), self.trace_len, flags, self.cost_N, 0)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -129,7 +133,8 @@ class BatchSolver:
                  status=torch.empty(stride, dtype=torch.int32, device=dev),
                  regu_rounds=torch.empty(stride, dtype=torch.int32, device=dev),
                  ls_total=torch.empty(stride, dtype=torch.int32, device=dev),
-                 regu_stages=torch.empty(stride, dtype=torch.int32, device=dev))
+                 regu_stages=torch.empty(stride, dtype=torch.int32, device=dev),
+                 last_search=torch.empty(stride, dtype=torch.int32, device=dev))
         if self.trace_len:
             T = self.trace_len
             o.update(ls_evals=torch.zeros((T, stride), dtype=torch.int32, device=dev),
@@ -187,7 +192,8 @@ class BatchSolver:
         return BatchResult(x=xs.permute(2, 0, 1).contiguous(), u=us.permute(2, 0, 1).contiguous(),
                            J0=out["J0"], J=out["J"], dmax=out["dmax"], max_abs_q=out["max_abs_q"],
                            iters=out["iters"], status=out["status"], regu_rounds=out["regu_rounds"],
-                           ls_total=out["ls_total"], regu_stages=out["regu_stages"], traces=tr)
+                           ls_total=out["ls_total"], regu_stages=out["regu_stages"], last_search=out["last_search"],
+                           traces=tr)
 
     def rollout_cost(self, x0, u):
         """Model.rollout + cost_trj for a batch: returns (x [B, N, nx], J [B])."""

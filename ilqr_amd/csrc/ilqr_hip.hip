@@ -60,7 +60,8 @@ __global__ __launch_bounds__(WG) void rollout_kernel(Dev a, const double* __rest
     const long st = a.p.stride;
     double xs[nx];
     for (int i = 0; i < nx; ++i) xs[i] = x0[(long)i * st + b];
-    double c = rollout_cost<M>(par_of<M>(a.p, b).get(), xs, CLane{u + b, st}, Lane{x + b, st}, a.p.N - 1);
+    double c = rollout_cost<M>(par_of<M>(a.p, b).get(), xs, CLane{u + b, st}, Lane{x + b, st}, a.p.N - 1,
+                               (a.p.cost_N ? a.p.cost_N : a.p.N) - 1);
     if (J) J[b] = c;
 }
 
@@ -170,6 +171,7 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
     if (p->stride < p->B) return fail(ILQR_E_BADARG, "stride must be >= B");
     if (!p->params) return fail(ILQR_E_BADARG, "params is NULL");
     if (p->max_iter < 0 || p->max_ls < 0 || p->trace_len < 0) return fail(ILQR_E_BADARG, "negative count");
+    if (p->cost_N < 0 || p->cost_N > p->N) return fail(ILQR_E_BADARG, "cost_N must be 0 (= N) or within 1..N");
     if ((p->flags & ILQR_FLAG_LAPACK_EIGVALS) && d.ndx + d.nu > 8)
         return fail(ILQR_E_BADARG, "ILQR_FLAG_LAPACK_EIGVALS is built for the plants solved one trajectory per lane");
     if ((p->flags & ILQR_FLAG_LS_SEQUENTIAL) && p->max_ls > 60)
@@ -178,7 +180,7 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
 }
 
 struct WsLayout {
-    size_t TA, TB, TOUT, G, Gscratch, dJ, J0, J, dmax, maxq, iters, status, regu_rounds, regu_stages, ls_total, idA, idB,
+    size_t TA, TB, TOUT, G, Gscratch, dJ, J0, J, dmax, maxq, iters, status, regu_rounds, regu_stages, ls_total, last_search, idA, idB,
         ls_slot, ls_dest, bt, bt2, ls_from, pred, win_ls, win_J, cnt, total;
 };
 WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
@@ -194,7 +196,7 @@ WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
     w.dJ = take(cap * 8);
     w.J0 = take(cap * 8); w.J = take(cap * 8); w.dmax = take(cap * 8); w.maxq = take(cap * 8);
     w.iters = take(cap * 4); w.status = take(cap * 4); w.regu_rounds = take(cap * 4); w.regu_stages = take(cap * 4);
-    w.ls_total = take(cap * 4);
+    w.ls_total = take(cap * 4); w.last_search = take(cap * 4);
     w.idA = take(cap * 4); w.idB = take(cap * 4); w.ls_slot = take(cap * 4); w.ls_dest = take(cap * 4);
     w.bt = take(cap * 4); w.bt2 = take(cap * 4);
     w.ls_from = take(cap * 4); w.pred = take(cap * 4);
@@ -215,7 +217,7 @@ Pipe part_of(Pipe a, long lo, long n, int part)
     a.x0 += lo; a.u += lo; a.x += lo;
     a.par += (M::NPAR > 8) ? lo * a.par_block : lo * a.par_pt;
     a.J0 += lo; a.J += lo; a.dmax += lo; a.maxq += lo;
-    a.iters += lo; a.status += lo; a.regu_rounds += lo; a.regu_stages += lo; a.ls_total += lo;
+    a.iters += lo; a.status += lo; a.regu_rounds += lo; a.regu_stages += lo; a.ls_total += lo; a.last_search += lo;
     if (a.tr_ls) a.tr_ls += lo;
     if (a.tr_acc) a.tr_acc += lo;
     if (a.tr_J) a.tr_J += lo;
@@ -258,6 +260,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     static_assert(Rec<M>::RT == (M::NX + M::NU + 7) / 8 * 8 && Rec<M>::RG == (M::NU + M::NU * M::NDX + 1) / 2 * 2, "");
     Pipe a;
     memset(&a, 0, sizeof(a));
+    a.SC = (p->cost_N ? p->cost_N : p->N) - 1;
     a.N = p->N; a.max_iter = p->max_iter; a.max_ls = p->max_ls; a.trace_len = p->trace_len; a.flags = p->flags;
     a.d_tol = p->d_tol; a.B = p->B; a.cap = p->stride; a.par = p->params;
     const bool per_traj = (p->flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY) != 0;
@@ -277,6 +280,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     a.regu_rounds = o.regu_rounds ? o.regu_rounds : (int32_t*)(ws + w.regu_rounds);
     a.regu_stages = o.regu_stages ? o.regu_stages : (int32_t*)(ws + w.regu_stages);
     a.ls_total = o.ls_total ? o.ls_total : (int32_t*)(ws + w.ls_total);
+    a.last_search = o.last_search ? o.last_search : (int32_t*)(ws + w.last_search);
     a.tr_ls = o.ls_evals; a.tr_acc = o.accepted; a.tr_J = o.J_trace; a.tr_dJ = o.deltaJ_trace;
     a.TA = (double*)(ws + w.TA); a.TB = (double*)(ws + w.TB); a.TOUT = (double*)(ws + w.TOUT); a.G = (double*)(ws + w.G); a.Gscratch = (double*)(ws + w.Gscratch); a.dJ = (double*)(ws + w.dJ);
     a.idA = (int32_t*)(ws + w.idA); a.idB = (int32_t*)(ws + w.idB);
@@ -393,7 +397,7 @@ int dispatch(int model_id, F&& f)
 extern "C" {
 
 const char* ilqr_last_error(void) { return g_err; }
-const char* ilqr_version(void) { return "ilqr_hip 0.2 (gfx950)"; }
+const char* ilqr_version(void) { return "ilqr_hip 0.3 (gfx950)"; }
 
 int ilqr_last_timing(ilqr_timing* out)
 {

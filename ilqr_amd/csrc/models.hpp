@@ -126,11 +126,18 @@ struct UserModel {
 #endif
 
 // ------------------------------------------------- RK4 (acrobot.py:76-97)
+// `euler`: one explicit Euler step instead, x + xdot dt (`integration` other than "RK4": acrobot.py:83-86,
+// Quadrotor_EA.py:139-142, Quadrotor_Quat.py:123-126).  The flag is the same for every lane of a launch that shares a
+// parameter block, so the branch is uniform.
 template <int NX, void (*XDOT)(const double*, const double*, double*)>
-__device__ inline void rk4_step(double dt, const double* x, const double* u, double* xn)
+__device__ inline void rk4_step(double dt, bool euler, const double* x, const double* u, double* xn)
 {
     double f1[NX], f2[NX], f3[NX], f4[NX], xs[NX];
     XDOT(x, u, f1);
+    if (euler) {
+        for (int i = 0; i < NX; ++i) xn[i] = x[i] + f1[i] * dt;
+        return;
+    }
     for (int i = 0; i < NX; ++i) xs[i] = x[i] + 0.5 * f1[i] * dt;
     XDOT(xs, u, f2);
     for (int i = 0; i < NX; ++i) xs[i] = x[i] + 0.5 * f2[i] * dt;
@@ -172,10 +179,17 @@ __device__ inline void rk4_chain(double c, double w, const double* A, const doub
 // stages, i.e. what CasADi's ca.jacobian of the RK4 graph evaluates
 // (acrobot.py:92-93, Quadrotor_EA.py:148-149, Quadrotor_Quat.py:132-133).
 template <int NX, int NU, void (*XDOTJAC)(const double*, const double*, double*, double*, double*)>
-__device__ inline void rk4_jac(double dt, const double* x, const double* u, double* Fx, double* Fu)
+__device__ inline void rk4_jac(double dt, bool euler, const double* x, const double* u, double* Fx, double* Fu)
 {
     double f[NX], xs[NX], A[NX * NX], B[NX * NU], Kx[NX * NX], Ku[NX * NU];
     XDOTJAC(x, u, f, Kx, Ku);
+    if (euler) {      // d(x + xdot dt)/dx = I + A dt, d/du = B dt
+        for (int i = 0; i < NX; ++i) {
+            for (int j = 0; j < NX; ++j) Fx[i * NX + j] = (i == j ? 1.0 : 0.0) + Kx[i * NX + j] * dt;
+            for (int j = 0; j < NU; ++j) Fu[i * NU + j] = Ku[i * NU + j] * dt;
+        }
+        return;
+    }
     for (int i = 0; i < NX * NX; ++i) Fx[i] = Kx[i];
     for (int i = 0; i < NX * NU; ++i) Fu[i] = Ku[i];
     for (int i = 0; i < NX; ++i) xs[i] = x[i] + 0.5 * f[i] * dt;
@@ -196,14 +210,18 @@ __device__ inline void rk4_jac(double dt, const double* x, const double* u, doub
 // Tangent of one RK4 step: d x_next along the direction (vx, vu), the same chain rule as rk4_jac applied
 // to one vector instead of the identity: d_i = A_i (vx + c_i d_(i-1)) + B_i vu.
 template <int NX, void (*XDOTJVP)(const double*, const double*, const double*, const double*, double*, double*)>
-__device__ inline void rk4_jvp(double dt, const double* x, const double* u, const double* vx, const double* vu,
+__device__ inline void rk4_jvp(double dt, bool euler, const double* x, const double* u, const double* vx, const double* vu,
                                double* dxn)
 {
     double f[NX], d[NX], acc[NX], xs[NX], vs[NX];
     for (int i = 0; i < NX; ++i) { acc[i] = 0.0; f[i] = 0.0; d[i] = 0.0; }
-    // one copy of the (large) generated function: the four stages run through the same code
+    // one copy of the (large) generated function: the four stages run through the same code (Euler: the first only).
+    // The trip count is kept the same for the whole wavefront (with a parameter block per trajectory `euler` is a
+    // per-lane value): a lane that integrates by Euler in a wavefront that also holds RK4 lanes idles through the
+    // other three stages with weight zero.
+    const int stages = (__ballot(!euler) != 0ull) ? 4 : 1;
 #pragma unroll 1
-    for (int stage = 0; stage < 4; ++stage) {
+    for (int stage = 0; stage < stages; ++stage) {
         const double c = (stage == 0) ? 0.0 : (stage == 3 ? 1.0 : 0.5);
         const double wgt = (stage == 0 || stage == 3) ? 1.0 : 2.0;
         for (int i = 0; i < NX; ++i) {
@@ -211,13 +229,27 @@ __device__ inline void rk4_jvp(double dt, const double* x, const double* u, cons
             vs[i] = (stage == 0) ? vx[i] : vx[i] + (c * dt) * d[i];
         }
         XDOTJVP(xs, u, vs, vu, f, d);
-        for (int i = 0; i < NX; ++i) acc[i] += wgt * d[i];
+        const bool counts = !euler || stage == 0;
+        for (int i = 0; i < NX; ++i) acc[i] += counts ? wgt * d[i] : 0.0;
     }
-    for (int i = 0; i < NX; ++i) dxn[i] = vx[i] + acc[i] * dt / 6.0;
+    for (int i = 0; i < NX; ++i) dxn[i] = euler ? vx[i] + acc[i] * dt : vx[i] + acc[i] * dt / 6.0;
+}
+
+// 0.5 e'We evaluated as ((0.5 e)' W) e  (acrobot.py:119-120, :127)
+template <int D>
+__device__ __forceinline__ double half_form(const double* W, const double* e)
+{
+    double s = 0.0;
+    for (int j = 0; j < D; ++j) {
+        double t = 0.0;
+        for (int i = 0; i < D; ++i) t += (0.5 * e[i]) * W[i * D + j];
+        s += t * e[j];
+    }
+    return s;
 }
 
 // --------------------- quadratic-cost RK4 plants (acrobot.py, Quadrotor_EA.py)
-// parameter block: [dt, Q(nx*nx), Qf(nx*nx), R(nu*nu), xref(nx), uref(nu)]
+// parameter block: [dt, Q(nx*nx), Qf(nx*nx), R(nu*nu), xref(nx), uref(nu), euler]   (euler != 0: Euler integration)
 template <int NX_, int NU_, bool UNROLL_, void (*XDOT)(const double*, const double*, double*),
           void (*XDOTJAC)(const double*, const double*, double*, double*, double*),
           void (*XDOTJVP)(const double*, const double*, const double*, const double*, double*, double*)>
@@ -226,12 +258,13 @@ struct QuadraticRK4Model {
     // 12 states + 4 controls: the backward pass runs with 16 lanes per trajectory (team_backward.hpp)
     static constexpr bool TEAM_BACKWARD = (NX_ == 12 && NU_ == 4);
     // one column (or any combination of columns) of [d x_next/dx, d x_next/du]
-    __device__ static void dynamics_jvp(const double* par, const double* x, const double* u, const double* vx,
+    __device__ static void dynamics_jvp(double dt, bool eul, const double* x, const double* u, const double* vx,
                                         const double* vu, double* dxn)
     {
-        rk4_jvp<NX, XDOTJVP>(par[0], x, u, vx, vu, dxn);
+        rk4_jvp<NX, XDOTJVP>(dt, eul, x, u, vx, vu, dxn);
     }
-    static constexpr int NPAR = 1 + 2 * NX * NX + NU * NU + NX + NU;
+    static constexpr int NPAR = 1 + 2 * NX * NX + NU * NU + NX + NU + 1;
+    __device__ static bool euler(const double* p) { return p[NPAR - 1] != 0.0; }
     static constexpr bool UNROLL = UNROLL_;
     static constexpr int BACKWARD_WAVES = 1;
     static constexpr long TAIL_COUNT = 8192;
@@ -243,19 +276,7 @@ struct QuadraticRK4Model {
 
     __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
     {
-        rk4_step<NX, XDOT>(par[0], x, u, xn);
-    }
-    // 0.5 e'We evaluated as ((0.5 e)' W) e  (acrobot.py:119-120, :127)
-    template <int D>
-    __device__ static double half_form(const double* W, const double* e)
-    {
-        double s = 0.0;
-        for (int j = 0; j < D; ++j) {
-            double t = 0.0;
-            for (int i = 0; i < D; ++i) t += (0.5 * e[i]) * W[i * D + j];
-            s += t * e[j];
-        }
-        return s;
+        rk4_step<NX, XDOT>(par[0], euler(par), x, u, xn);
     }
     __device__ static double cost_stage(const double* par, const double* x, const double* u)
     {
@@ -274,7 +295,7 @@ struct QuadraticRK4Model {
     __device__ static void stage(const double* par, const double* x, const double* u, double* lx, double* lu,
                                  double* lxx, double* lux, double* luu, double* fx, double* fu)
     {
-        rk4_jac<NX, NU, XDOTJAC>(par[0], x, u, fx, fu);
+        rk4_jac<NX, NU, XDOTJAC>(par[0], euler(par), x, u, fx, fu);
         const double *Q = Qm(par), *R = Rm(par);
         for (int i = 0; i < NX; ++i) {
             double s = 0.0;
@@ -311,46 +332,118 @@ using AcrobotModel = QuadraticRK4Model<4, 1, true, acrobot_gen_xdot, acrobot_gen
 using QuadEAModel = QuadraticRK4Model<12, 4, false, quad_ea_gen_xdot, quad_ea_gen_xdot_jac, quad_ea_gen_xdot_jvp>;
 
 // ------------------------------------ quaternion quadrotor (Quadrotor_Quat.py)
-// parameter block: [dt, qdiag(12), qfdiag(12), rdiag(4), xref(13), uref(4)]
+// parameter block: [dt, Q(12x12), Qf(12x12), R(4x4), xref(13), uref(4), euler]; Q, Qf, R any matrices, row-major
 struct QuadQuatModel {
-    static constexpr int NX = 13, NU = 4, NDX = 12, NPAR = 1 + 12 + 12 + 4 + 13 + 4;
+    static constexpr int NX = 13, NU = 4, NDX = 12, NPAR = 1 + 144 + 144 + 16 + 13 + 4 + 1;
     static constexpr bool UNROLL = false;
     static constexpr bool TEAM_BACKWARD = true;      // 16 lanes per trajectory (team_backward.hpp)
     static constexpr int BACKWARD_WAVES = 1;
     static constexpr long TAIL_COUNT = 8192;
-    __device__ static const double* qd(const double* p) { return p + 1; }
-    __device__ static const double* qfd(const double* p) { return p + 13; }
-    __device__ static const double* rd(const double* p) { return p + 25; }
-    __device__ static const double* xref(const double* p) { return p + 29; }
-    __device__ static const double* uref(const double* p) { return p + 42; }
+    __device__ static const double* Qm(const double* p) { return p + 1; }
+    __device__ static const double* Qf(const double* p) { return p + 145; }
+    __device__ static const double* Rm(const double* p) { return p + 289; }
+    __device__ static const double* xref(const double* p) { return p + 305; }
+    __device__ static const double* uref(const double* p) { return p + 318; }
+    __device__ static bool euler(const double* p) { return p[NPAR - 1] != 0.0; }
 
-    // generated cost functions take w = [xref(13), uref(4), qdiag(12), rdiag(4)]
-    __device__ static void weights(const double* par, bool fin, double* w)
-    {
-        for (int i = 0; i < 13; ++i) w[i] = xref(par)[i];
-        for (int i = 0; i < 4; ++i) w[13 + i] = uref(par)[i];
-        const double* q = fin ? qfd(par) : qd(par);
-        for (int i = 0; i < 12; ++i) w[17 + i] = q[i];
-        for (int i = 0; i < 4; ++i) w[29 + i] = rd(par)[i];
-    }
     __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
     {
-        rk4_step<13, quad_quat_gen_xdot>(par[0], x, u, xn);
+        rk4_step<13, quad_quat_gen_xdot>(par[0], euler(par), x, u, xn);
+    }
+    // state_err = Gx(x)' (x - xref)  (Quadrotor_Quat.py:150): three attitude entries, nine differences
+    __device__ static void state_err(const double* par, const double* x, double* e)
+    {
+        quad_quat_gen_err(xref(par), x, e);
+        for (int i = 0; i < 9; ++i) e[3 + i] = x[4 + i] - xref(par)[4 + i];
     }
     __device__ static double cost_stage(const double* par, const double* x, const double* u)
     {
-        double w[33], c;
-        weights(par, false, w);
-        quad_quat_gen_cost(w, x, u, &c);
-        return c;
+        double e[12], du[4];
+        state_err(par, x, e);
+        for (int i = 0; i < 4; ++i) du[i] = u[i] - uref(par)[i];
+        return half_form<12>(Qm(par), e) + half_form<4>(Rm(par), du);          // Quadrotor_Quat.py:152
     }
     __device__ static double cost_final(const double* par, const double* x)
     {
-        double w[33], c;
-        weights(par, true, w);
-        quad_quat_gen_cost(w, x, uref(par), &c);   // u = uref: the action term vanishes (Quadrotor_Quat.py:153)
-        return c;
+        double e[12];
+        state_err(par, x, e);
+        return half_form<12>(Qf(par), e);                                       // Quadrotor_Quat.py:153
     }
+    // Derivatives of c = 0.5 e'We (+ 0.5 du'R du unless fin) in the 13-dim state, W = Q or Qf
+    // (what ca.jacobian gives, Quadrotor_Quat.py:158-175): with Ws = (W + W')/2, s = Ws e and J = de/dx,
+    //   l_x = s'J,  l_xx = J' Ws J + sum_i s_i d2e_i/dx2,  l_u = Rs du,  Rs = (R + R')/2.
+    // J = blkdiag(da/dq [3x4], I9); only the three attitude entries of e have second derivatives.
+    // Ws [12x12] and Rs [4x4] come in symmetrised (sym_weight below).  `work`: COST_WORK doubles for e, da/dq and the
+    // Hessians of a (a caller short of registers hands in memory that is not private).
+    static constexpr int COST_WORK = 12 + 12 + 48;
+    __device__ static void cost_derivs_sym(const double* Ws, const double* Rs, const double* xr, const double* ur,
+                                           bool fin, const double* x, const double* u, double* l13, double* lu,
+                                           double* l13x13, double* work)
+    {
+        double* const e = work;
+        double* const Ja = work + 12;
+        double* const Ha = work + 24;
+        double s[12];
+        quad_quat_gen_err_derivs(xr, x, e, Ja, Ha);
+        for (int i = 0; i < 9; ++i) e[3 + i] = x[4 + i] - xr[4 + i];
+        for (int i = 0; i < 12; ++i) {
+            double a = 0.0;
+            for (int j = 0; j < 12; ++j) a += Ws[i * 12 + j] * e[j];
+            s[i] = a;
+        }
+        for (int b = 0; b < 4; ++b) l13[b] = s[0] * Ja[b] + s[1] * Ja[4 + b] + s[2] * Ja[8 + b];
+        for (int c = 0; c < 9; ++c) l13[4 + c] = s[3 + c];
+        double T[12];      // Ws[0..2][0..2] Ja   (3 x 4)
+        for (int i = 0; i < 3; ++i)
+            for (int b = 0; b < 4; ++b) {
+                double t = 0.0;
+                for (int j = 0; j < 3; ++j) t += Ws[i * 12 + j] * Ja[j * 4 + b];
+                T[i * 4 + b] = t;
+            }
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                double t = 0.0;
+                for (int i = 0; i < 3; ++i) t += Ja[i * 4 + a] * T[i * 4 + b] + s[i] * Ha[i * 16 + a * 4 + b];
+                l13x13[a * 13 + b] = t;
+            }
+        for (int a = 0; a < 4; ++a)
+            for (int c = 0; c < 9; ++c) {
+                double t = 0.0;
+                for (int i = 0; i < 3; ++i) t += Ja[i * 4 + a] * Ws[i * 12 + 3 + c];
+                l13x13[a * 13 + 4 + c] = t;
+                l13x13[(4 + c) * 13 + a] = t;
+            }
+        for (int c = 0; c < 9; ++c)
+            for (int d = 0; d < 9; ++d) l13x13[(4 + c) * 13 + 4 + d] = Ws[(3 + c) * 12 + 3 + d];
+        for (int i = 0; i < 4; ++i) {
+            double t = 0.0;
+            if (!fin)
+                for (int j = 0; j < 4; ++j) t += Rs[i * 4 + j] * (u[j] - ur[j]);
+            lu[i] = t;
+        }
+    }
+    // entry e of [(Q + Q')/2 (144), (Qf + Qf')/2 (144), (R + R')/2 (16)]
+    static constexpr int SYM_WEIGHTS = 144 + 144 + 16;
+    __device__ static double sym_weight(const double* par, int e)
+    {
+        if (e < 288) {
+            const double* const W = (e < 144) ? Qm(par) : Qf(par);
+            const int q = (e < 144) ? e : e - 144, i = q / 12, j = q % 12;
+            return 0.5 * (W[i * 12 + j] + W[j * 12 + i]);
+        }
+        const int q = e - 288;
+        return luu(par, q / 4, q % 4);
+    }
+    __device__ static void cost_derivs(const double* par, bool fin, const double* x, const double* u, double* l13,
+                                       double* lu, double* l13x13)
+    {
+        double Ws[144], Rs[16], work[COST_WORK];
+        for (int e = 0; e < 144; ++e) Ws[e] = sym_weight(par, (fin ? 144 : 0) + e);
+        for (int e = 0; e < 16; ++e) Rs[e] = sym_weight(par, 288 + e);
+        cost_derivs_sym(Ws, Rs, xref(par), uref(par), fin, x, u, l13, lu, l13x13, work);
+    }
+    // l_uu = (R + R')/2
+    __device__ static double luu(const double* par, int i, int j) { return 0.5 * (Rm(par)[i * 4 + j] + Rm(par)[j * 4 + i]); }
     // The state Jacobian Gx = blkdiag(G(q)[4x3], I9) (Quadrotor_Quat.py:142-144)
     // is applied block-wise: only the quaternion rows/columns need arithmetic.
     //   out[12 x C] = Gx' * in[13 x C]
@@ -383,20 +476,19 @@ struct QuadQuatModel {
     __device__ static void stage(const double* par, const double* x, const double* u, double* lx, double* lu,
                                  double* lxx, double* lux, double* luu, double* fx, double* fu)
     {
-        double w[33], G[12];
+        double G[12];
         double l13[13], l13x13[169], T[12 * 13];
-        weights(par, false, w);
         quad_quat_gen_G(x, G);
-        quad_quat_gen_cost_derivs(w, x, u, l13, lu, l13x13);
+        cost_derivs(par, false, x, u, l13, lu, l13x13);
         proj_right<1>(G, l13, lx);                 // (l_x G)
         projT_left<13>(G, l13x13, T);              // G' l_xx       [12 x 13]
         proj_right<12>(G, T, lxx);                 // (G' l_xx) G   [12 x 12]
         for (int i = 0; i < 4 * 12; ++i) lux[i] = 0.0;   // l_ux = 0, so l_ux G = 0
-        for (int i = 0; i < 16; ++i) luu[i] = 0.0;
-        for (int i = 0; i < 4; ++i) luu[i * 4 + i] = rd(par)[i];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) luu[i * 4 + j] = QuadQuatModel::luu(par, i, j);
         {
             double A[169], B[52];
-            rk4_jac<13, 4, quad_quat_gen_xdot_jac>(par[0], x, u, A, B);
+            rk4_jac<13, 4, quad_quat_gen_xdot_jac>(par[0], euler(par), x, u, A, B);
             projT_left<13>(G, A, T);               // G' A
             proj_right<12>(G, T, fx);              // G' A G
             projT_left<4>(G, B, fu);               // G' B
@@ -405,10 +497,9 @@ struct QuadQuatModel {
     // Quadrotor_Quat.py:259-265
     __device__ static void final(const double* par, const double* x, double* Vx, double* Vxx)
     {
-        double w[33], G[12], v13[13], vu[4], v13x13[169], T[12 * 13];
-        weights(par, true, w);
+        double G[12], v13[13], vu[4], v13x13[169], T[12 * 13];
         quad_quat_gen_G(x, G);
-        quad_quat_gen_cost_derivs(w, x, uref(par), v13, vu, v13x13);
+        cost_derivs(par, true, x, uref(par), v13, vu, v13x13);
         projT_left<13>(G, v13x13, T);
         proj_right<12>(G, T, Vxx);
         proj_right<1>(G, v13, Vx);

@@ -55,6 +55,7 @@ static_assert(PIPE_WG == 64, "backward_stage assumes single-wavefront workgroups
 struct Pipe {
     // problem
     int N, max_iter, max_ls, trace_len, flags;
+    int SC;                    // stage costs a trajectory's cost sums (ilqr_problem::cost_N - 1; N - 1 by default)
     double d_tol;
     long B, cap;               // trajectories, slot capacity (= stride of the caller's arrays)
     const double* par;
@@ -67,7 +68,7 @@ struct Pipe {
     double* x;
     // per-trajectory state, indexed by id (caller's output arrays or workspace)
     double *J0, *J, *dmax, *maxq;
-    int32_t *iters, *status, *regu_rounds, *regu_stages, *ls_total;
+    int32_t *iters, *status, *regu_rounds, *regu_stages, *ls_total, *last_search;
     // optional traces [trace_len][cap]
     int32_t* tr_ls;
     uint8_t* tr_acc;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
     double xs[nx];
     for (int i = 0; i < nx; ++i) xs[i] = a.x0[(long)i * a.cap + b];
     const Dest<M> out{a.TA + b * Rec<M>::RT, a.cap * Rec<M>::RT};
-    const double J = rollout_cost_rec<M>(params_of<M, PT>(a, b).get(), xs, CLane{a.u + b, a.cap}, out, S);     // iLQRController.py:27-34
+    const double J = rollout_cost_rec<M>(params_of<M, PT>(a, b).get(), xs, CLane{a.u + b, a.cap}, out, S, a.SC);     // iLQRController.py:27-34
     a.idA[b] = (int)b;
     a.J0[b] = J;
     a.J[b] = J;
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
     a.regu_rounds[b] = 0;
     a.regu_stages[b] = 0;
     a.ls_total[b] = 0;
+    a.last_search[b] = 0;
     a.pred[b] = 0;
 }
 
@@ -277,6 +279,7 @@ __device__ __forceinline__ void record_search(const Pipe& a, int id, int ls, boo
         if (a.tr_J) a.tr_J[q] = Jn;
     }
     a.ls_total[id] += ls;
+    a.last_search[id] = complete ? 1 : 2;                                             // :69-74
     a.J[id] = Jn;                                                                     // :79
 }
 
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward1_kernel(Pipe 
         const RecIn T = slot_T<M>(a.TA, a.cap, s);
         const Dest<M> d = make_dest<M>(a, dest, id);
         const double J = a.J[id], deltaJ = a.dJ[s];
-        const double Jn = forward_pass<M>(params_of<M, PT>(a, id).get(), T, slot_G<M>(a, s), 1.0, d, a.N - 1);  // :63-64
+        const double Jn = forward_pass<M>(params_of<M, PT>(a, id).get(), T, slot_G<M>(a, s), 1.0, d, a.N - 1, a.SC);  // :63-64
         const bool complete = (Jn - J <= -1e-2 * 1.0 * deltaJ) && (1 < a.max_ls);      // :66
         const bool abandon = (Jn != Jn) || (1 >= a.max_ls);                            // :67
         if (complete || abandon) {
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward_level_kernel(
         const RecIn T = slot_T<M>(a.TA, a.cap, s);
         const Dest<M> d = make_dest<M>(a, dest, id);
         const double J = a.J[id], deltaJ = a.dJ[s];
-        const double Jn = forward_pass<M>(params_of<M, PT>(a, id).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1);
+        const double Jn = forward_pass<M>(params_of<M, PT>(a, id).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1, a.SC);
         const bool complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);   // :66
         const bool abandon = (Jn != Jn) || (ls >= a.max_ls);                           // :67
         if (complete || abandon) {
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_backtrack_group_kerne
             if (pending && ls <= a.max_ls) {
                 double alpha = 1.0;
                 for (int i = 1; i < ls; ++i) alpha *= 0.5;                                 // :73
-                Jn = forward_cost<M>(par.get(), slot_T<M>(a.TA, a.cap, s), slot_G<M>(a, s), alpha, a.N - 1);
+                Jn = forward_cost<M>(par.get(), slot_T<M>(a.TA, a.cap, s), slot_G<M>(a, s), alpha, a.N - 1, a.SC);
                 complete = (Jn - J <= -1e-2 * alpha * deltaJ) && (ls < a.max_ls);          // :66
                 stop = complete || (Jn != Jn) || (ls >= a.max_ls);                         // :67
             }
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_commit_kernel(Pipe a,
     if (complete) {
         double alpha = 1.0;
         for (int i = 1; i < ls; ++i) alpha *= 0.5;
-        forward_pass<M>(params_of<M, PT>(a, id).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1);
+        forward_pass<M>(params_of<M, PT>(a, id).get(), T, slot_G<M>(a, s), alpha, d, a.N - 1, a.SC);
     } else {
         copy_traj<M>(T, d, a.N - 1);
     }

@@ -917,7 +917,8 @@ __device__ __forceinline__ bool backward_pass(const double* par, const RecIn& T,
 // the final cost).  Strided arrays in and out.
 // ------------------------------------------------------------------
 template <class M>
-__device__ __forceinline__ double rollout_cost(const double* par, const double* x0, const CLane& U, const Lane& X, int S)
+__device__ __forceinline__ double rollout_cost(const double* par, const double* x0, const CLane& U, const Lane& X, int S,
+                                               int SC)
 {
     constexpr int nx = M::NX, m = M::NU;
     double x[nx], xn[nx], u[m];
@@ -926,7 +927,7 @@ __device__ __forceinline__ double rollout_cost(const double* par, const double* 
     double total = 0.0;
     for (int k = 0; k < S; ++k) {
         load_vec<m>(U, k, u);
-        total += M::cost_stage(par, x, u);
+        if (k < SC) total += M::cost_stage(par, x, u);
         M::dynamics(par, x, u, xn);
         for (int i = 0; i < nx; ++i) x[i] = xn[i];
         store_vec<nx>(X, k + 1, x);
@@ -937,7 +938,8 @@ __device__ __forceinline__ double rollout_cost(const double* par, const double* 
 
 // The same with the trajectory written as T records (u copied along).
 template <class M>
-__device__ __forceinline__ double rollout_cost_rec(const double* par, const double* x0, const CLane& U, const Dest<M>& out, int S)
+__device__ __forceinline__ double rollout_cost_rec(const double* par, const double* x0, const CLane& U, const Dest<M>& out, int S,
+                                                   int SC)
 {
     constexpr int nx = M::NX, m = M::NU;
     double x[nx], xn[nx], u[m];
@@ -946,7 +948,7 @@ __device__ __forceinline__ double rollout_cost_rec(const double* par, const doub
     for (int k = 0; k < S; ++k) {
         load_vec<m>(U, k, u);
         out.stage(k, x, u);
-        total += M::cost_stage(par, x, u);
+        if (k < SC) total += M::cost_stage(par, x, u);
         M::dynamics(par, x, u, xn);
         for (int i = 0; i < nx; ++i) x[i] = xn[i];
     }
@@ -965,7 +967,7 @@ __device__ __forceinline__ double rollout_cost_rec(const double* par, const doub
 // were seen in which that came out as 0 for a callee with a 676-byte frame -- a memory aperture violation.)
 template <class M, bool WRITE = true>
 __device__ __forceinline__ double forward_pass(const double* par, const RecIn& T, const RecIn& G, double alpha,
-                                      const Dest<M>& out, int S)
+                                      const Dest<M>& out, int S, int SC)
 {
     constexpr int n = M::NDX, m = M::NU, nx = M::NX;
     double xn[nx], xu[nx + m], xnext[nx], g[m + m * n], dx[n], un[m], xu2[nx + m], g2[m + m * n];
@@ -989,7 +991,7 @@ __device__ __forceinline__ double forward_pass(const double* par, const RecIn& T
             un[i] = (xu[nx + i] + alpha * d[i]) + s;
         }
         if (WRITE) out.stage(k, xn, un);
-        total += M::cost_stage(par, xn, un);
+        if (k < SC) total += M::cost_stage(par, xn, un);
         M::dynamics(par, xn, un, xnext);
         for (int i = 0; i < nx; ++i) xn[i] = xnext[i];
     }
@@ -1000,9 +1002,9 @@ __device__ __forceinline__ double forward_pass(const double* par, const RecIn& T
 
 // The same evaluation without storing the candidate (cost only).
 template <class M>
-__device__ __forceinline__ double forward_cost(const double* par, const RecIn& T, const RecIn& G, double alpha, int S)
+__device__ __forceinline__ double forward_cost(const double* par, const RecIn& T, const RecIn& G, double alpha, int S, int SC)
 {
-    return forward_pass<M, false>(par, T, G, alpha, Dest<M>{nullptr, 0}, S);
+    return forward_pass<M, false>(par, T, G, alpha, Dest<M>{nullptr, 0}, S, SC);
 }
 
 // Copy of a trajectory (all T records) to `out`.

@@ -90,9 +90,9 @@ __device__ inline int team_has_negative_eig(double* Lr, double diag, int i, unsi
 //   SHARED            doubles of LDS per workgroup for data common to all teams (filled by setup)
 //   EXTRA             doubles of LDS per team for the plant's own scratch
 //   setup             once per kernel
-//   column            column j of [f_x f_u] at (x, u)                         -> col[12]
+//   column            column j of [f_x f_u] at (x, u), integrator step dt / kind given -> col[12]
 //   cost_row          l_z[j] and row j of l_zz = [[l_xx, l_ux'], [l_ux, l_uu]] -> lz, lzz[16]
-//   final_row         V_x[j] and row j of V_xx at the last knot point (j < 12)  -> vx, vrow[12]
+//   final_row         V_x[j] and row j of V_xx at the last knot point (j < 12)  -> vx, vrow[12]  (shared as above)
 // ------------------------------------------------------------------
 template <class M>
 struct TeamOps;
@@ -126,14 +126,14 @@ struct TeamOps<QuadraticRK4Model<12, 4, U, XD, XJ, XV>> {
             shared[e] = v;
         }
     }
-    __device__ static void column(const double* par, const double* xu, int j, double*, double* col)
+    __device__ static void column(double dt, bool eul, const double* xu, int j, double*, double* col)
     {
         double vx[n], vu[m];
 #pragma unroll
         for (int c = 0; c < n; ++c) vx[c] = (c == j) ? 1.0 : 0.0;
 #pragma unroll
         for (int c = 0; c < m; ++c) vu[c] = (c + n == j) ? 1.0 : 0.0;
-        M::dynamics_jvp(par, xu, xu + n, vx, vu, col);
+        M::dynamics_jvp(dt, eul, xu, xu + n, vx, vu, col);
     }
     __device__ static void cost_row(const double* par, const double* xu, int j, const double* shared, double*,
                                     double& lz, double* lzz)
@@ -148,7 +148,8 @@ struct TeamOps<QuadraticRK4Model<12, 4, U, XD, XJ, XV>> {
         for (int c = 0; c < m; ++c) su += lzz[n + c] * (xu[n + c] - M::uref(par)[c]);
         lz = (j < n) ? sx : su;
     }
-    __device__ static void final_row(const double* par, const double* x, int j, double*, double& vx, double* vrow)
+    __device__ static void final_row(const double* par, const double* x, int j, const double*, double*, double& vx,
+                                     double* vrow)
     {
         double sx = 0.0;
         const int jj = (j < n) ? j : 0;
@@ -168,9 +169,23 @@ template <>
 struct TeamOps<QuadQuatModel> {
     using M = QuadQuatModel;
     static constexpr int n = 12, m = 4, w = 16;
-    static constexpr int SHARED = 0, EXTRA = 13 + 4 + 169;
-    __device__ static void setup(const double*, int, double*) {}
-    __device__ static void setup_team(const double*, int, double*) {}
+    // shared: the symmetrised weights [(Q + Q')/2, (Qf + Qf')/2, (R + R')/2], formed once per kernel, then xref (13)
+    // and uref (4): inside the stage loop nothing is read through the parameter pointer
+    static constexpr int XREF = M::SYM_WEIGHTS, UREF = XREF + 13, SHARED = UREF + 4 + 1, EXTRA = 13 + 4 + 169 + 1 + M::COST_WORK;
+    __device__ static double shared_entry(const double* par, int e)
+    {
+        if (e < XREF) return M::sym_weight(par, e);
+        if (e < UREF) return M::xref(par)[e - XREF];
+        return (e < UREF + 4) ? M::uref(par)[e - UREF] : 0.0;
+    }
+    __device__ static void setup(const double* par, int lane, double* shared)
+    {
+        for (int e = lane; e < SHARED; e += PIPE_WG) shared[e] = shared_entry(par, e);
+    }
+    __device__ static void setup_team(const double* par, int j, double* shared)
+    {
+        for (int e = j; e < SHARED; e += TEAM_LANES) shared[e] = shared_entry(par, e);
+    }
     // entry (t, c) of Gx [13 x 12]
     __device__ static double gx(const double* G, int t, int c)
     {
@@ -188,7 +203,7 @@ struct TeamOps<QuadQuatModel> {
         for (int t = 4; t < 13; ++t) pick = (t - 1 == c) ? v[t] : pick;
         return (c < 3) ? s : pick;
     }
-    __device__ static void column(const double* par, const double* xu, int j, double*, double* col)
+    __device__ static void column(double dt, bool eul, const double* xu, int j, double*, double* col)
     {
         double G[12], vx[13], vu[m], dxn[13];
         quad_quat_gen_G(xu, G);
@@ -196,7 +211,7 @@ struct TeamOps<QuadQuatModel> {
         for (int t = 0; t < 13; ++t) vx[t] = (j < n) ? gx(G, t, j) : 0.0;
 #pragma unroll
         for (int c = 0; c < m; ++c) vu[c] = (c + n == j) ? 1.0 : 0.0;
-        rk4_jvp<13, quad_quat_gen_xdot_jvp>(par[0], xu, xu + 13, vx, vu, dxn);
+        rk4_jvp<13, quad_quat_gen_xdot_jvp>(dt, eul, xu, xu + 13, vx, vu, dxn);
         // Gx' (A v): rows 0..2 through G, the rest shifted by one
 #pragma unroll
         for (int i = 0; i < n; ++i) {
@@ -228,29 +243,28 @@ struct TeamOps<QuadQuatModel> {
 #pragma unroll
         for (int c = 0; c < n; ++c) row[c] = times_gx(G, T1, c);
     }
-    __device__ static void cost_row(const double* par, const double* xu, int j, const double*, double* ex,
+    __device__ static void cost_row(const double* par, const double* xu, int j, const double* shared, double* ex,
                                     double& lz, double* lzz)
     {
-        double wgt[33], G[12];
-        M::weights(par, false, wgt);
+        double G[12];
         quad_quat_gen_G(xu, G);
         // every lane of the team writes the same values: l_x (13), l_u (4), l_xx (13 x 13)
-        quad_quat_gen_cost_derivs(wgt, xu, xu + 13, ex, ex + 13, ex + 17);
+        M::cost_derivs_sym(shared, shared + 288, shared + XREF, shared + UREF, false, xu, xu + 13, ex, ex + 13, ex + 17, ex + 187);
         wave_sync();
         double gj, row[n];
         project_row(G, ex, (j < n) ? j : 0, gj, row);
 #pragma unroll
         for (int c = 0; c < n; ++c) lzz[c] = (j < n) ? row[c] : 0.0;                      // l_ux = 0
 #pragma unroll
-        for (int c = 0; c < m; ++c) lzz[n + c] = (j >= n && c == j - n) ? M::rd(par)[c] : 0.0;   // l_uu = diag(rd)
+        for (int c = 0; c < m; ++c) lzz[n + c] = (j >= n) ? shared[288 + (j - n) * 4 + c] : 0.0;     // l_uu = (R + R')/2
         lz = (j < n) ? gj : ex[13 + (j - n)];
     }
-    __device__ static void final_row(const double* par, const double* x, int j, double* ex, double& vx, double* vrow)
+    __device__ static void final_row(const double* par, const double* x, int j, const double* shared, double* ex,
+                                     double& vx, double* vrow)
     {
-        double wgt[33], G[12];
-        M::weights(par, true, wgt);
+        double G[12];
         quad_quat_gen_G(x, G);
-        quad_quat_gen_cost_derivs(wgt, x, M::uref(par), ex, ex + 13, ex + 17);
+        M::cost_derivs_sym(shared + 144, shared + 288, shared + XREF, shared + UREF, true, x, shared + UREF, ex, ex + 13, ex + 17, ex + 187);
         wave_sync();
         project_row(G, ex, (j < n) ? j : 0, vx, vrow);
     }
@@ -281,6 +295,9 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
     double* const Gp = live ? a.G + (long)s * Rec<M>::RG : a.Gscratch;
     const long Gss = live ? a.cap * Rec<M>::RG : Rec<M>::RG;
     const int it = a.iters[id] + 1;                                                  // iLQRController.py:46
+    // the integrator's step and kind: read once (with a parameter block per trajectory they are per-lane values)
+    const double step_dt = par[0];
+    const bool step_euler = M::euler(par);
 
     if constexpr (PT) OPS::setup_team(par, j, shared_all + team * OPS::SHARED);
     else OPS::setup(par, lane, shared_all);
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
     load_rec<nx>(T.p + (long)S * T.ss, xu);
     {
         double vxj, vrow[n];
-        OPS::final_row(par, xu, j, EX, vxj, vrow);
+        OPS::final_row(par, xu, j, PT ? shared_all + team * OPS::SHARED : shared_all, EX, vxj, vrow);
         if (j < n) {
 #pragma unroll
             for (int c = 0; c < n; ++c) L[tl::V + j * n + c] = vrow[c];
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
         const bool alive = live && ok;
         // ---- column j of F = [f_x f_u]: derivative of the RK4 step along unit vector j
         double col[n];
-        OPS::column(par, xu, j, EX, col);
+        OPS::column(step_dt, step_euler, xu, j, EX, col);
         wave_sync();        // everybody is done with the previous stage's LDS data
 #pragma unroll
         for (int r = 0; r < n; ++r) L[tl::F + r * w + j] = col[r];

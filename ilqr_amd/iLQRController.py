@@ -54,19 +54,31 @@ class iLQR:
                 f"{type(model).__name__} has no generated device code: use CarModel, Acrobot2DModel, "
                 "QuadrotorEAModel or QuadrotorQuatModel from ilqr_amd.models, or define the plant through "
                 "ilqr_amd.models.user.UserModel")
-        mN = getattr(model, "N", None)
-        if mN is not None and int(mN) != int(N):
-            # the plants' cost_trj sums over the MODEL's N (acrobot.py:139); the kernels use one horizon
-            raise ValueError(f"model.N ({mN}) must equal the solver horizon N ({N})")
+
+    def _cost_N(self) -> int:
+        """Knot points cost_trj sums over.  The acrobot's and the quadrotors' cost_trj sum the stage costs of
+        the MODEL's horizon and the final cost of the last state (acrobot.py:139, Quadrotor_EA.py:199,
+        Quadrotor_Quat.py:212), whatever horizon the solver runs; Model.cost_trj (model.py:31-37: car, plants
+        written by a user) sums over the trajectory it is given."""
+        if not getattr(self.model, "_cost_sums_model_horizon", False):
+            return 0
+        mN = int(self.model.N)
+        if mN > self.N:
+            raise IndexError(f"index {self.N - 1} is out of bounds: the model's cost_trj sums {mN - 1} stages of a "
+                             f"trajectory of {self.N - 1} (model.N = {mN}, solver N = {self.N})")
+        if mN < 1:
+            raise ValueError("model.N must be >= 1")
+        return 0 if mN == self.N else mN
 
     # ------------------------------------------------------------------
     def _get_solver(self) -> BatchSolver:
         par = np.ascontiguousarray(self.model._param_block(), dtype=np.float64)
-        key = (par.tobytes(), self.N, self.max_iter, self.max_linesearch_iters, float(self.d_tol), self.trace_len)
+        cost_N = self._cost_N()
+        key = (par.tobytes(), self.N, self.max_iter, self.max_linesearch_iters, float(self.d_tol), self.trace_len, cost_N)
         if self._solver is None or key != self._solver_key:
             self._solver = BatchSolver(self.model._model_id, par, self.N, self.max_iter, self.max_linesearch_iters,
                                        self.d_tol, device=self.device, trace_len=self.trace_len,
-                                       library=getattr(self.model, "_library", None))
+                                       library=getattr(self.model, "_library", None), cost_N=cost_N)
             self._solver_key = key
         return self._solver
 
@@ -87,17 +99,17 @@ class iLQR:
             res = solver.solve(x0a, u_trj)
         self.info = res
         status = res.status.cpu().numpy()
-        # reference counters: reset at every iteration that reaches the line search (:57-58),
-        # so after the call they describe the last such iteration
-        if res.traces:
-            acc = res.traces["accepted"].cpu().numpy()
-            lse = res.traces["ls_evals"].cpu().numpy()
-            searched = (lse > 0)
-            last = np.where(searched.any(1), searched.shape[1] - 1 - np.argmax(searched[:, ::-1], axis=1), -1)
-            ok = np.array([acc[b, last[b]] if last[b] >= 0 else 0 for b in range(len(last))])
-            self.num_ls_success = int(ok[0]) if single else ok.astype(int)
-            self.num_ls_fails = (int(last[0] >= 0 and not ok[0]) if single
-                                 else ((last >= 0) & (ok == 0)).astype(int))
+        # reference counters: reset at every iteration that reaches the line search (:57-58), so after the call
+        # they describe the last such iteration; a call none of whose iterations got there leaves them alone
+        last = res.last_search.cpu().numpy()
+        if single:
+            if last[0] != 0:
+                self.num_ls_success, self.num_ls_fails = int(last[0] == 1), int(last[0] == 2)
+        else:
+            old_s = np.broadcast_to(np.asarray(self.num_ls_success), last.shape)
+            old_f = np.broadcast_to(np.asarray(self.num_ls_fails), last.shape)
+            self.num_ls_success = np.where(last == 0, old_s, last == 1).astype(int)
+            self.num_ls_fails = np.where(last == 0, old_f, last == 2).astype(int)
         if single and status[0] == _lib.EXIT_LINALG:
             raise np.linalg.LinAlgError("Array must not contain infs or NaNs, or Q_uu is singular "
                                         "(iLQRController.py:110, :126)")

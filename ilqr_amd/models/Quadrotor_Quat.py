@@ -1,5 +1,5 @@
 """Quaternion quadrotor with a 12-dim error state, drop-in for
-control/models/Quadrotor_Quat.py:31-275 (diagonal Q, Qf, R)."""
+control/models/Quadrotor_Quat.py:31-275 (Q, Qf [12 x 12] and R [4 x 4] any matrices, as there)."""
 from __future__ import annotations
 
 import numpy as np
@@ -15,12 +15,6 @@ class QuadrotorQuatModel(QuadraticCostModel):
 
     def __init__(self, Q, Qf, R, dt=0.01, N=20, integration="RK4", **kwargs):
         super().__init__(Q, Qf, R, dt, N, integration, **kwargs)
-        for name, W in (("Q", self.Q), ("Qf", self.Qf), ("R", self.R)):
-            if np.count_nonzero(W - np.diag(np.diag(W))):
-                raise NotImplementedError(f"{name} must be diagonal for the generated quaternion cost")
-
-    def _weights_block(self):
-        return np.concatenate([[self.dt], np.diag(self.Q), np.diag(self.Qf), np.diag(self.R)])
 
     def CalcDifferentialState(self, state, ref_state):
         """Quadrotor_Quat.py:218-228: G(state)' (state - ref_state), 12-vector."""

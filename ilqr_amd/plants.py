@@ -245,16 +245,21 @@ def quat_state_diff_jacobian(x):
     return J
 
 
-def quat_cost(x, u, xref, uref, Qd, Rd, with_action=True):
-    """Quadrotor_Quat.py:150-153 with diagonal weights Qd[12], Rd[4]
-    (0.5 e^T Q e + 0.5 du^T R du,  e = Gx(x)^T (x - xref))."""
+def quat_state_error(x, xref):
+    """Quadrotor_Quat.py:150: state_err = Gx(x)^T (x - xref), 12 entries (the first three through G(q))."""
     Gx = quat_state_diff_jacobian(x)
     dx = [x[i] - xref[i] for i in range(13)]
-    e = [sum(Gx[i][j] * dx[i] for i in range(13)) for j in range(12)]
-    c = 0.5 * sum(Qd[j] * e[j] * e[j] for j in range(12))
+    return [sum(Gx[i][j] * dx[i] for i in range(13)) for j in range(12)]
+
+
+def quat_cost(x, u, xref, uref, Q, R, with_action=True):
+    """Quadrotor_Quat.py:150-153: 0.5 e^T Q e + 0.5 du^T R du with e = quat_state_error, Q [12][12] and R [4][4]
+    any matrices (rows of numbers or symbols)."""
+    e = quat_state_error(x, xref)
+    c = 0.5 * sum(e[i] * Q[i][j] * e[j] for i in range(12) for j in range(12))
     if with_action:
         du = [u[i] - uref[i] for i in range(4)]
-        c = c + 0.5 * sum(Rd[i] * du[i] * du[i] for i in range(4))
+        c = c + 0.5 * sum(du[i] * R[i][j] * du[j] for i in range(4) for j in range(4))
     return c
 
 

@@ -24,9 +24,11 @@ extern "C" {
 
 /* plant models; parameter block layouts (doubles, device memory):
  *   CAR        [r, v_target]                               control/models/car.py:55-61
- *   ACROBOT    [dt, Q(4x4), Qf(4x4), R(1x1), xref(4), uref(1)]      control/models/acrobot.py:6-19,101-103
- *   QUAD_EA    [dt, Q(12x12), Qf(12x12), R(4x4), xref(12), uref(4)] control/models/Quadrotor_EA.py:23-43,157-159
- *   QUAD_QUAT  [dt, qdiag(12), qfdiag(12), rdiag(4), xref(13), uref(4)]  control/models/Quadrotor_Quat.py:39-59,178-180
+ *   ACROBOT    [dt, Q(4x4), Qf(4x4), R(1x1), xref(4), uref(1), euler]        control/models/acrobot.py:6-19,76-86,101-103
+ *   QUAD_EA    [dt, Q(12x12), Qf(12x12), R(4x4), xref(12), uref(4), euler]   control/models/Quadrotor_EA.py:23-43,132-142,157-159
+ *   QUAD_QUAT  [dt, Q(12x12), Qf(12x12), R(4x4), xref(13), uref(4), euler]   control/models/Quadrotor_Quat.py:39-59,116-126,150-153,178-180
+ *   Q, Qf, R: any matrices, row-major (the reference never asks for symmetry).  euler: 0 = the RK4 step
+ *   (integration="RK4"), anything else = one explicit Euler step x + xdot dt (any other `integration`).
  *              (diagonal weights only)
  * matrices are row-major. */
 enum { ILQR_MODEL_CAR = 0, ILQR_MODEL_ACROBOT = 1, ILQR_MODEL_QUAD_EA = 2, ILQR_MODEL_QUAD_QUAT = 3,
@@ -61,6 +63,12 @@ typedef struct {
                              ILQR_FLAG_PARAMS_PER_TRAJECTORY) */
     int32_t trace_len;    /* rows of the optional per-iteration traces (0 = none) */
     int32_t flags;        /* ILQR_FLAG_* */
+    int32_t cost_N;       /* knot points the trajectory cost sums over: stage costs of stages 0 .. cost_N-2, then the
+                             final cost of the LAST state of the trajectory.  0 = N.  The reference's acrobot and
+                             quadrotor plants sum over the horizon they were constructed with, whatever horizon the
+                             solver runs (acrobot.py:139, Quadrotor_EA.py:199, Quadrotor_Quat.py:212);
+                             1 <= cost_N <= N (the reference raises IndexError beyond) */
+    int32_t reserved_;    /* 0 */
 } ilqr_problem;
 
 /* Line-search evaluation schedule (the result does not depend on it, bit for bit):
@@ -131,6 +139,9 @@ typedef struct {
     uint8_t *accepted;   /* trace: 1 if the search of iteration it was accepted (:69) */
     double *J_trace;     /* trace: Jn after the search of iteration it (:79) */
     double *deltaJ_trace;/* trace: expected reduction of iteration it (:49) */
+    int32_t *last_search;/* the last line search of this call: 0 no iteration reached it, 1 it accepted a
+                          * candidate, 2 it was abandoned: num_ls_success / num_ls_fails as the reference leaves
+                          * them after run_ilqr (iLQRController.py:57-58, :69-74) */
 } ilqr_outputs;
 
 /* model.get_dims(): control/models/model.py:9-10.  npar = doubles in the parameter block. */

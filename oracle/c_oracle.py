@@ -76,6 +76,8 @@ def lib(path=None):
         L.ilqr_oracle_has_negative_eig_lapack.argtypes = [dp, C.c_int, dp]
         L.ilqr_oracle_set_psd_rule.restype = None
         L.ilqr_oracle_set_psd_rule.argtypes = [C.c_int]
+        L.ilqr_oracle_set_cost_N.restype = None
+        L.ilqr_oracle_set_cost_N.argtypes = [C.c_int]
         L.ilqr_oracle_has_negative_eig_ldl.restype = C.c_int
         L.ilqr_oracle_has_negative_eig_ldl.argtypes = [dp, C.c_int, dp]
         L.ilqr_oracle_unit_qterms.restype = None
@@ -101,10 +103,11 @@ def info_size():
     return INFO_DTYPE.itemsize
 
 
-def solve_batch(model, par, N, max_iter, max_ls, d_tol, x0, u, nthreads=0, library=None, rule="lapack"):
+def solve_batch(model, par, N, max_iter, max_ls, d_tol, x0, u, nthreads=0, library=None, rule="lapack", cost_N=0):
     """x0[B,nx], u[B,N-1,nu] (not modified) -> dict(x[B,N,nx], u[B,N-1,nu], info structured array).
     rule: how `np.any(np.linalg.eigvals(Q) < 0)` is decided -- "lapack" (DGEEV restated: the reference's own verdicts)
-    or "ldl" (the LDL' rule of the HIP kernels: the kernels' algorithm on the CPU)."""
+    or "ldl" (the LDL' rule of the HIP kernels: the kernels' algorithm on the CPU).
+    cost_N: knot points the trajectory cost sums over when the plant was built with another horizon than N (0 = N)."""
     mid = MODEL_IDS[model] if isinstance(model, str) else model
     nx, nu, ndx, npar = dims(mid, library)
     par = np.ascontiguousarray(par, dtype=np.float64)
@@ -117,9 +120,11 @@ def solve_batch(model, par, N, max_iter, max_ls, d_tol, x0, u, nthreads=0, libra
     if nthreads <= 0:
         nthreads = len(os.sched_getaffinity(0))
     lib(library).ilqr_oracle_set_psd_rule(dict(lapack=0, ldl=1)[rule])
+    lib(library).ilqr_oracle_set_cost_N(0 if int(cost_N) == int(N) else int(cost_N))
     rc = lib(library).ilqr_oracle_solve_batch(mid, _p(par), N, max_iter, max_ls, float(d_tol), B, _p(x0), _p(u), _p(x),
                                        info.ctypes.data_as(C.c_void_p), nthreads)
     lib(library).ilqr_oracle_set_psd_rule(0)
+    lib(library).ilqr_oracle_set_cost_N(0)
     assert rc == 0
     return dict(x=x, u=u, info=info)
 
@@ -153,12 +158,12 @@ def pack_car(r, v_target):
     return np.array([r, v_target], dtype=np.float64)
 
 
-def pack_quadratic(dt, Q, Qf, R, xref, uref):
+def pack_quadratic(dt, Q, Qf, R, xref, uref, euler=False):
+    """[dt, Q, Qf, R, xref, uref, euler]: the block of the acrobot and of both quadrotors (full matrices, row-major;
+    euler: `integration` other than "RK4")."""
     return np.concatenate([[dt], np.asarray(Q, float).ravel(), np.asarray(Qf, float).ravel(),
                            np.asarray(R, float).ravel(), np.asarray(xref, float).ravel(),
-                           np.asarray(uref, float).ravel()])
+                           np.asarray(uref, float).ravel(), [1.0 if euler else 0.0]])
 
 
-def pack_quat(dt, Q, Qf, R, xref, uref):
-    return np.concatenate([[dt], np.diag(Q), np.diag(Qf), np.diag(R), np.asarray(xref, float).ravel(),
-                           np.asarray(uref, float).ravel()]).astype(np.float64)
+pack_quat = pack_quadratic

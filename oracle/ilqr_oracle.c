@@ -274,10 +274,15 @@ static void rollout(const ilqr_oracle_model *M, const double *par, const double 
 
 /* control/models/model.py:31-37 and the overrides acrobot.py:129-142,
  * Quadrotor_EA.py:185-200, Quadrotor_Quat.py:201-216 (same summation order) */
+static int g_cost_N = 0;
+/* The overrides sum the stage costs of the horizon the PLANT was constructed with (`range(self.N-1)`), then the
+ * final cost of the trajectory's last state; 0 = the trajectory's own length (model.py:31-37). */
+void ilqr_oracle_set_cost_N(int cost_N) { g_cost_N = cost_N; }
 static double cost_trj(const ilqr_oracle_model *M, const double *par, const double *x, const double *u, int S)
 {
     double total = 0.0;
-    for (int k = 0; k < S; ++k) total += M->cost_stage(par, x + k * M->nx, u + k * M->nu);
+    const int SC = g_cost_N > 0 ? g_cost_N - 1 : S;
+    for (int k = 0; k < SC; ++k) total += M->cost_stage(par, x + k * M->nx, u + k * M->nu);
     total += M->cost_final(par, x + S * M->nx);
     return total;
 }

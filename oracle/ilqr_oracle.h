@@ -59,6 +59,7 @@ typedef struct {
 
 int ilqr_oracle_solve(const ilqr_oracle_model *M, const double *par, int N, int max_iter, int max_ls, double d_tol,
                       const double *x0, double *u, double *x, ilqr_oracle_info *info);
+void ilqr_oracle_set_cost_N(int cost_N);   /* knot points cost_trj sums over; 0 = the trajectory's length */
 int ilqr_oracle_solve_batch(int model_id, const double *par, int N, int max_iter, int max_ls, double d_tol, long B,
                             const double *x0, double *u, double *x, ilqr_oracle_info *info, int nthreads);
 const ilqr_oracle_model *ilqr_oracle_get_model(int model_id);

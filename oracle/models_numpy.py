@@ -265,16 +265,21 @@ def quat_state_diff_jacobian(x):
     return J
 
 
-def quat_cost(x, u, xref, uref, Qd, Rd, with_action=True):
-    """Quadrotor_Quat.py:150-153 with diagonal weights Qd[12], Rd[4]
-    (0.5 e^T Q e + 0.5 du^T R du,  e = Gx(x)^T (x - xref))."""
+def quat_state_error(x, xref):
+    """Quadrotor_Quat.py:150: state_err = Gx(x)^T (x - xref), 12 entries (the first three through G(q))."""
     Gx = quat_state_diff_jacobian(x)
     dx = [x[i] - xref[i] for i in range(13)]
-    e = [sum(Gx[i][j] * dx[i] for i in range(13)) for j in range(12)]
-    c = 0.5 * sum(Qd[j] * e[j] * e[j] for j in range(12))
+    return [sum(Gx[i][j] * dx[i] for i in range(13)) for j in range(12)]
+
+
+def quat_cost(x, u, xref, uref, Q, R, with_action=True):
+    """Quadrotor_Quat.py:150-153: 0.5 e^T Q e + 0.5 du^T R du with e = quat_state_error, Q [12][12] and R [4][4]
+    any matrices (rows of numbers or symbols)."""
+    e = quat_state_error(x, xref)
+    c = 0.5 * sum(e[i] * Q[i][j] * e[j] for i in range(12) for j in range(12))
     if with_action:
         du = [u[i] - uref[i] for i in range(4)]
-        c = c + 0.5 * sum(Rd[i] * du[i] * du[i] for i in range(4))
+        c = c + 0.5 * sum(du[i] * R[i][j] * du[j] for i in range(4) for j in range(4))
     return c
 
 
@@ -345,6 +350,14 @@ def rk4_with_jacobians(lam: _Lambdified, x, u, dt):
 # cost_trj, Q_terms, CalcDifferentialState: control/models/model.py:15-53) are
 # the ones that run when Base is the imported reference class.
 # --------------------------------------------------------------------------
+def step_with_jacobians(lam, x, u, dt, euler):
+    """(x_next, d x_next/dx, d x_next/du) of the RK4 step, or of the Euler step x + xdot dt."""
+    if not euler:
+        return rk4_with_jacobians(lam, x, u, dt)
+    x = np.asarray(x, dtype=np.float64); u = np.asarray(u, dtype=np.float64)
+    return x + lam.f(x, u) * dt, np.eye(len(x)) + lam.A(x, u) * dt, lam.B(x, u) * dt
+
+
 def make_models(Base):
     class CarModel(Base):
         """control/models/car.py:54-102."""
@@ -399,7 +412,7 @@ def make_models(Base):
             self.ndx = self.nx
             self.xref = np.zeros(self.nx)
             self.uref = np.zeros(self.nu)
-            assert integration == "RK4"
+            self.euler = integration != "RK4"          # acrobot.py:76-86
             key = type(self).__name__
             if key not in _QuadraticRK4Model._lam_cache:
                 _QuadraticRK4Model._lam_cache[key] = _Lambdified(type(self)._xdot, self.nx, self.nu)
@@ -413,6 +426,8 @@ def make_models(Base):
             f = self.lam.f
             dt = self.dt
             f1 = f(x, u)
+            if self.euler:
+                return x + f1 * dt
             f2 = f(x + 0.5 * f1 * dt, u)
             f3 = f(x + 0.5 * f2 * dt, u)
             f4 = f(x + 1.0 * f3 * dt, u)
@@ -435,7 +450,7 @@ def make_models(Base):
             return J
 
         def stage(self, x, u):
-            _, f_x, f_u = rk4_with_jacobians(self.lam, x, u, self.dt)
+            _, f_x, f_u = step_with_jacobians(self.lam, x, u, self.dt, self.euler)
             l_x = self.Q @ (x - self.xref)
             l_u = self.R @ (u - self.uref)
             return l_x, l_u, self.Q, np.zeros((self.nu, self.nx)), self.R, f_x, f_u
@@ -452,66 +467,72 @@ def make_models(Base):
         _dims = (12, 4)
 
     class QuadrotorQuatModel(Base):
-        """control/models/Quadrotor_Quat.py:31-275 (diagonal Q, Qf, R only)."""
+        """control/models/Quadrotor_Quat.py:31-275; Q, Qf [12 x 12] and R [4 x 4] any matrices."""
         _cache = {}
 
         def __init__(self, Q, Qf, R, dt=0.01, N=20, integration="RK4", **kwargs):
             self.nx, self.nu, self.ndx = 13, 4, 12
-            self.Q, self.Qf, self.R, self.dt, self.N = Q, Qf, R, dt, N
-            for W in (Q, Qf, R):
-                assert np.count_nonzero(W - np.diag(np.diag(W))) == 0, "diagonal weights only"
+            self.Q, self.Qf, self.R = (np.asarray(W, dtype=np.float64) for W in (Q, Qf, R))
+            self.dt, self.N = dt, N
             self.xref = np.zeros(13)
             self.uref = np.zeros(4)
-            assert integration == "RK4"
+            self.euler = integration != "RK4"          # Quadrotor_Quat.py:116-126
             if "lam" not in self._cache:
                 self._cache["lam"] = _Lambdified(quad_quat_xdot, 13, 4)
+                xs = sp.symbols("x0:13", real=True)
+                self._cache["G"] = sp.lambdify(list(xs), sp.Matrix(quat_state_diff_jacobian(list(xs))), "numpy", cse=True)
+            self.lam = self._cache["lam"]
+            # the cost and its derivatives are differentiated with this plant's weights written in as numbers
+            # (entries that are zero drop out of the expressions); one set of functions per pair of weights
+            self._fn = {False: self._cost_functions(self.Q, self.R), True: self._cost_functions(self.Qf, self.R)}
+
+        def _cost_functions(self, W, R):
+            key = (W.tobytes(), R.tobytes())
+            if key not in self._cache:
                 xs = sp.symbols("x0:13", real=True)
                 us = sp.symbols("u0:4", real=True)
                 xr = sp.symbols("xr0:13", real=True)
                 ur = sp.symbols("ur0:4", real=True)
-                qd = sp.symbols("qd0:12", real=True)
-                rd = sp.symbols("rd0:4", real=True)
-                c = quat_cost(list(xs), list(us), list(xr), list(ur), list(qd), list(rd))
+                num = lambda A: [[sp.Float(float(v)) if v != 0 else 0 for v in row] for row in A]
+                c = quat_cost(list(xs), list(us), list(xr), list(ur), num(W), num(R))
                 cx = sp.Matrix([c]).jacobian(xs)
                 cu = sp.Matrix([c]).jacobian(us)
-                args = list(xs) + list(us) + list(xr) + list(ur) + list(qd) + list(rd)
-                ex = dict(c=sp.Matrix([c]), l_x=cx, l_u=cu, l_xx=cx.jacobian(xs),
-                          l_ux=cu.jacobian(xs), l_uu=cu.jacobian(us),
-                          G=sp.Matrix(quat_state_diff_jacobian(list(xs))))
-                self._cache["sym"] = dict(x=xs, u=us, xr=xr, ur=ur, qd=qd, rd=rd, **ex)
-                self._cache["fn"] = {k: sp.lambdify(args, v, "numpy", cse=True) for k, v in ex.items()}
-            self.lam = self._cache["lam"]
-            self._fn = self._cache["fn"]
+                args = list(xs) + list(us) + list(xr) + list(ur)
+                ex = dict(c=sp.Matrix([c]), l_x=cx, l_u=cu, l_xx=cx.jacobian(xs), l_ux=cu.jacobian(xs),
+                          l_uu=cu.jacobian(us))
+                self._cache[key] = {k: sp.lambdify(args, v, "numpy", cse=True) for k, v in ex.items()}
+            return self._cache[key]
 
         def set_references(self, xref, uref):
             self.xref, self.uref = xref, uref
 
-        def _ev(self, key, x, u, W, shp):
+        def _ev(self, key, x, u, final, shp):
             u = np.zeros(4) if u is None else u
-            a = (*np.asarray(x).ravel(), *np.asarray(u).ravel(), *self.xref, *self.uref,
-                 *np.diag(W), *np.diag(self.R))
-            return np.asarray(self._fn[key](*a), dtype=np.float64).reshape(shp)
+            a = (*np.asarray(x).ravel(), *np.asarray(u).ravel(), *self.xref, *self.uref)
+            return np.asarray(self._fn[final][key](*a), dtype=np.float64).reshape(shp)
 
         def G(self, x):
-            return self._ev("G", x, None, self.Q, (13, 12))
+            return np.asarray(self._cache["G"](*np.asarray(x).ravel()), dtype=np.float64).reshape(13, 12)
 
         def discrete_dynamics(self, x, u):
             x = np.asarray(x, dtype=np.float64).ravel(); u = np.asarray(u, dtype=np.float64).ravel()
             f = self.lam.f
             dt = self.dt
             f1 = f(x, u)
+            if self.euler:
+                return x + f1 * dt
             f2 = f(x + 0.5 * f1 * dt, u)
             f3 = f(x + 0.5 * f2 * dt, u)
             f4 = f(x + 1.0 * f3 * dt, u)
             return x + (f1 + 2 * f2 + 2 * f3 + f4) * dt / 6.0
 
         def _cost_stage(self, x, u, xref, uref):
-            return float(self._ev("c", x, u, self.Q, ()))
+            return float(self._ev("c", x, u, False, ()))
 
         def _cost_final(self, xf, xref):
             # terminal cost = state part only, weights Qf (Quadrotor_Quat.py:153);
-            # evaluate the stage expression at u = uref so the action term is 0.
-            return float(self._ev("c", xf, self.uref, self.Qf, ()))
+            # evaluate the expression at u = uref so the action term is 0.
+            return float(self._ev("c", xf, self.uref, True, ()))
 
         def cost_trj(self, xtraj, utraj):
             J = 0
@@ -525,21 +546,21 @@ def make_models(Base):
             return self.G(state).T @ (np.asarray(state) - np.asarray(ref_state))
 
         def stage(self, x, u):
-            _, A, B = rk4_with_jacobians(self.lam, x, u, self.dt)
+            _, A, B = step_with_jacobians(self.lam, x, u, self.dt, self.euler)
             G = self.G(x)
             f_x = G.T @ A @ G
             f_u = G.T @ B
-            l_x = self._ev("l_x", x, u, self.Q, (1, 13))
-            l_u = self._ev("l_u", x, u, self.Q, (1, 4))
-            l_xx = self._ev("l_xx", x, u, self.Q, (13, 13))
-            l_uu = self._ev("l_uu", x, u, self.Q, (4, 4))
-            l_ux = self._ev("l_ux", x, u, self.Q, (4, 13))
+            l_x = self._ev("l_x", x, u, False, (1, 13))
+            l_u = self._ev("l_u", x, u, False, (1, 4))
+            l_xx = self._ev("l_xx", x, u, False, (13, 13))
+            l_uu = self._ev("l_uu", x, u, False, (4, 4))
+            l_ux = self._ev("l_ux", x, u, False, (4, 13))
             return l_x, l_u, l_xx, l_ux, l_uu, f_x, f_u
 
         def final(self, x):
             G = self.G(x)
-            Vxn = self._ev("l_x", x, self.uref, self.Qf, (1, 13))
-            Vxxn = self._ev("l_xx", x, self.uref, self.Qf, (13, 13))
+            Vxn = self._ev("l_x", x, self.uref, True, (1, 13))
+            Vxxn = self._ev("l_xx", x, self.uref, True, (13, 13))
             V_xx = G.T @ Vxxn @ G
             V_x = Vxn @ G
             return V_x.T.ravel(), V_xx

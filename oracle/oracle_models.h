@@ -111,8 +111,10 @@ static void car_final_derivs(const double *par, const double *x, double *Vx, dou
 DEF_DIFF_SUB(car_diff, 5)
 
 /* ------------------- RK4 plants with quadratic cost ------------------- */
-/* parameter block: [dt, Q(nx*nx), Qf(nx*nx), R(nu*nu), xref(nx), uref(nu)] */
+/* parameter block: [dt, Q(nx*nx), Qf(nx*nx), R(nu*nu), xref(nx), uref(nu), euler]; euler != 0: one explicit
+ * Euler step instead of RK4 (`integration` other than "RK4": acrobot.py:83-86, Quadrotor_EA.py:139-142) */
 #define QP_DT(p) ((p)[0])
+#define QP_EULER(p, nx, nu) ((p)[1 + 2 * (nx) * (nx) + (nu) * (nu) + (nx) + (nu)] != 0.0)
 #define QP_Q(p, nx, nu) ((p) + 1)
 #define QP_QF(p, nx, nu) ((p) + 1 + (nx) * (nx))
 #define QP_R(p, nx, nu) ((p) + 1 + 2 * (nx) * (nx))
@@ -123,10 +125,14 @@ typedef void (*xdot_fn)(const double *x, const double *u, double *f);
 typedef void (*xdot_jac_fn)(const double *x, const double *u, double *f, double *A, double *B);
 
 /* acrobot.py:76-82: f2 = f(x + 0.5*f1*dt), ..., x + (f1 + 2 f2 + 2 f3 + f4)*dt/6.0 */
-static void rk4_step(xdot_fn f, int nx, double dt, const double *x, const double *u, double *xn)
+static void rk4_step(xdot_fn f, int nx, double dt, int euler, const double *x, const double *u, double *xn)
 {
     double f1[ILQR_MAX_NX], f2[ILQR_MAX_NX], f3[ILQR_MAX_NX], f4[ILQR_MAX_NX], xs[ILQR_MAX_NX];
     f(x, u, f1);
+    if (euler) {      /* acrobot.py:86: x + xdot * dt */
+        for (int i = 0; i < nx; ++i) xn[i] = x[i] + f1[i] * dt;
+        return;
+    }
     for (int i = 0; i < nx; ++i) xs[i] = x[i] + 0.5 * f1[i] * dt;
     f(xs, u, f2);
     for (int i = 0; i < nx; ++i) xs[i] = x[i] + 0.5 * f2[i] * dt;
@@ -160,13 +166,20 @@ static void rk4_chain(int nx, int nu, double c, const double *A, const double *B
 }
 
 /* d x_next / d x (nx x nx) and d x_next / d u (nx x nu) of the RK4 step */
-static void rk4_jac(xdot_jac_fn fj, int nx, int nu, double dt, const double *x, const double *u, double *Fx,
+static void rk4_jac(xdot_jac_fn fj, int nx, int nu, double dt, int euler, const double *x, const double *u, double *Fx,
                     double *Fu)
 {
     double f[ILQR_MAX_NX], xs[ILQR_MAX_NX];
     double A[ILQR_MAX_NX * ILQR_MAX_NX], B[ILQR_MAX_NX * ILQR_MAX_NU];
     double Kx[4][ILQR_MAX_NX * ILQR_MAX_NX], Ku[4][ILQR_MAX_NX * ILQR_MAX_NU];
     fj(x, u, f, Kx[0], Ku[0]);
+    if (euler) {      /* d(x + xdot dt)/dx = I + A dt, d/du = B dt */
+        for (int i = 0; i < nx; ++i) {
+            for (int j = 0; j < nx; ++j) Fx[i * nx + j] = (i == j ? 1.0 : 0.0) + Kx[0][i * nx + j] * dt;
+            for (int j = 0; j < nu; ++j) Fu[i * nu + j] = Ku[0][i * nu + j] * dt;
+        }
+        return;
+    }
     for (int i = 0; i < nx; ++i) xs[i] = x[i] + 0.5 * f[i] * dt;
     fj(xs, u, f, A, B);
     rk4_chain(nx, nu, 0.5 * dt, A, B, Kx[0], Ku[0], Kx[1], Ku[1]);
@@ -203,7 +216,7 @@ static double quad_form_half(const double *W, const double *e, int n)
 #define DEF_QUADRATIC_MODEL(P, NX, NU, XDOT, XDOTJAC)                                                         \
     static void P##_dynamics(const double *par, const double *x, const double *u, double *xn)                 \
     {                                                                                                         \
-        rk4_step(XDOT, NX, QP_DT(par), x, u, xn);                                                             \
+        rk4_step(XDOT, NX, QP_DT(par), QP_EULER(par, NX, NU), x, u, xn);                                                            \
     }                                                                                                         \
     static double P##_cost_stage(const double *par, const double *x, const double *u)                         \
     {                                                                                                         \
@@ -222,7 +235,7 @@ static double quad_form_half(const double *W, const double *e, int n)
                                  double *lxx, double *lux, double *luu, double *fx, double *fu)               \
     {                                                                                                         \
         const double *Q = QP_Q(par, NX, NU), *R = QP_R(par, NX, NU);                                          \
-        rk4_jac(XDOTJAC, NX, NU, QP_DT(par), x, u, fx, fu);                                                   \
+        rk4_jac(XDOTJAC, NX, NU, QP_DT(par), QP_EULER(par, NX, NU), x, u, fx, fu);                                                  \
         for (int i = 0; i < NX; ++i) {                                                                        \
             double s = 0.0;                                                                                   \
             for (int j = 0; j < NX; ++j) s += Q[i * NX + j] * (x[j] - QP_XREF(par, NX, NU)[j]);               \
@@ -253,21 +266,23 @@ DEF_QUADRATIC_MODEL(acrobot, 4, 1, oracle_acrobot_xdot, oracle_acrobot_xdot_jac)
 DEF_QUADRATIC_MODEL(quad_ea, 12, 4, oracle_quad_ea_xdot, oracle_quad_ea_xdot_jac)
 
 /* --------------------------- quaternion quadrotor --------------------------- */
-/* parameter block: [dt, qdiag(12), qfdiag(12), rdiag(4), xref(13), uref(4)] */
+/* parameter block: [dt, Q(12 x 12), Qf(12 x 12), R(4 x 4), xref(13), uref(4), euler] */
 #define QQ_DT(p) ((p)[0])
-#define QQ_QD(p) ((p) + 1)
-#define QQ_QFD(p) ((p) + 13)
-#define QQ_RD(p) ((p) + 25)
-#define QQ_XREF(p) ((p) + 29)
-#define QQ_UREF(p) ((p) + 42)
+#define QQ_Q(p) ((p) + 1)
+#define QQ_QF(p) ((p) + 145)
+#define QQ_R(p) ((p) + 289)
+#define QQ_XREF(p) ((p) + 305)
+#define QQ_UREF(p) ((p) + 318)
+#define QQ_EULER(p) ((p)[322] != 0.0)
+#define QQ_W 177
 
 static void qq_weights(const double *par, int final, double *w)
 {
-    /* the cost functions of plants_ad.cpp take w = [xref(13), uref(4), qdiag(12), rdiag(4)] */
+    /* the cost functions of plants_ad.cpp take w = [xref(13), uref(4), Q(12 x 12), R(4 x 4)] */
     memcpy(w, QQ_XREF(par), 13 * sizeof(double));
     memcpy(w + 13, QQ_UREF(par), 4 * sizeof(double));
-    memcpy(w + 17, final ? QQ_QFD(par) : QQ_QD(par), 12 * sizeof(double));
-    memcpy(w + 29, QQ_RD(par), 4 * sizeof(double));
+    memcpy(w + 17, final ? QQ_QF(par) : QQ_Q(par), 144 * sizeof(double));
+    memcpy(w + 161, QQ_R(par), 16 * sizeof(double));
 }
 /* Quadrotor_Quat.py:142-144: Gx = blkdiag(G(q), I9), 13 x 12 */
 static void qq_state_jac(const double *x, double *Gx)
@@ -281,11 +296,11 @@ static void qq_state_jac(const double *x, double *Gx)
 }
 static void quad_quat_dynamics(const double *par, const double *x, const double *u, double *xn)
 {
-    rk4_step(oracle_quad_quat_xdot, 13, QQ_DT(par), x, u, xn);
+    rk4_step(oracle_quad_quat_xdot, 13, QQ_DT(par), QQ_EULER(par), x, u, xn);
 }
 static double quad_quat_cost_stage(const double *par, const double *x, const double *u)
 {
-    double w[33], c;
+    double w[QQ_W], c;
     qq_weights(par, 0, w);
     oracle_quad_quat_cost(w, x, u, &c);
     return c;
@@ -293,7 +308,7 @@ static double quad_quat_cost_stage(const double *par, const double *x, const dou
 static double quad_quat_cost_final(const double *par, const double *x)
 {
     /* Quadrotor_Quat.py:153: state part only, weights Qf; u = uref zeroes the action term */
-    double w[33], c;
+    double w[QQ_W], c;
     qq_weights(par, 1, w);
     oracle_quad_quat_cost(w, x, QQ_UREF(par), &c);
     return c;
@@ -302,13 +317,13 @@ static double quad_quat_cost_final(const double *par, const double *x)
 static void quad_quat_stage_derivs(const double *par, const double *x, const double *u, double *lx, double *lu,
                                    double *lxx, double *lux, double *luu, double *fx, double *fu)
 {
-    double w[33], A[169], B[52], Gx[156], T[156];
+    double w[QQ_W], A[169], B[52], Gx[156], T[156];
     qq_weights(par, 0, w);
     oracle_quad_quat_cost_derivs(w, x, u, lx, lu, lxx);
     memset(lux, 0, sizeof(double) * 4 * 13);
-    memset(luu, 0, sizeof(double) * 16);
-    for (int i = 0; i < 4; ++i) luu[i * 4 + i] = QQ_RD(par)[i];
-    rk4_jac(oracle_quad_quat_xdot_jac, 13, 4, QQ_DT(par), x, u, A, B);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) luu[i * 4 + j] = 0.5 * (QQ_R(par)[i * 4 + j] + QQ_R(par)[j * 4 + i]);
+    rk4_jac(oracle_quad_quat_xdot_jac, 13, 4, QQ_DT(par), QQ_EULER(par), x, u, A, B);
     qq_state_jac(x, Gx);
     /* T = G^T A (12x13); fx = T G (12x12) */
     for (int i = 0; i < 12; ++i)
@@ -333,7 +348,7 @@ static void quad_quat_stage_derivs(const double *par, const double *x, const dou
 /* Quadrotor_Quat.py:259-265 */
 static void quad_quat_final_derivs(const double *par, const double *x, double *Vx, double *Vxx)
 {
-    double w[33], vx[13], vu[4], vxx[169], Gx[156], T[156];
+    double w[QQ_W], vx[13], vu[4], vxx[169], Gx[156], T[156];
     qq_weights(par, 1, w);
     oracle_quad_quat_cost_derivs(w, x, QQ_UREF(par), vx, vu, vxx);
     qq_state_jac(x, Gx);
@@ -435,11 +450,11 @@ static const ilqr_oracle_model *oracle_model_table(int id)
     static const ilqr_oracle_model T[4] = {
         {5, 2, 5, 2, car_dynamics, car_cost_stage, car_cost_final, car_stage_derivs, car_final_derivs, car_diff,
          q_terms_default_export},
-        {4, 1, 4, 1 + 16 + 16 + 1 + 4 + 1, acrobot_dynamics, acrobot_cost_stage, acrobot_cost_final,
+        {4, 1, 4, 1 + 16 + 16 + 1 + 4 + 1 + 1, acrobot_dynamics, acrobot_cost_stage, acrobot_cost_final,
          acrobot_stage_derivs, acrobot_final_derivs, acrobot_diff, q_terms_default_export},
-        {12, 4, 12, 1 + 144 + 144 + 16 + 12 + 4, quad_ea_dynamics, quad_ea_cost_stage, quad_ea_cost_final,
+        {12, 4, 12, 1 + 144 + 144 + 16 + 12 + 4 + 1, quad_ea_dynamics, quad_ea_cost_stage, quad_ea_cost_final,
          quad_ea_stage_derivs, quad_ea_final_derivs, quad_ea_diff, q_terms_default_export},
-        {13, 4, 12, 1 + 12 + 12 + 4 + 13 + 4, quad_quat_dynamics, quad_quat_cost_stage, quad_quat_cost_final,
+        {13, 4, 12, 1 + 144 + 144 + 16 + 13 + 4 + 1, quad_quat_dynamics, quad_quat_cost_stage, quad_quat_cost_final,
          quad_quat_stage_derivs, quad_quat_final_derivs, quad_quat_diff, q_terms_quat},
     };
     return (id >= 0 && id < 4) ? &T[id] : 0;

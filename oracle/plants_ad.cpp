@@ -265,27 +265,33 @@ void quad_quat_xdot(const T* x, const T* u, T* f)
     f[12] = (R[2][2] * thrust - QM * 9.81) / QM;
 }
 
-// 0.5 e' diag(qd) e + 0.5 du' diag(rd) du, e = Gx(x)' (x - xref)   (Quadrotor_Quat.py:142-153)
+// ((0.5 e)' W) e for a D x D row-major matrix of plain numbers
+template <class T, int D>
+T half_form(const double* W, const T* e)
+{
+    T total = lift(e[0], 0.0);
+    for (int j = 0; j < D; ++j) {
+        T t = W[0 * D + j] * (0.5 * e[0]);
+        for (int i = 1; i < D; ++i) t = t + W[i * D + j] * (0.5 * e[i]);
+        total = total + t * e[j];
+    }
+    return total;
+}
+// 0.5 e' Q e + 0.5 du' R du, e = Gx(x)' (x - xref), Q [12 x 12] and R [4 x 4] any matrices
+// (Quadrotor_Quat.py:142-153)
 template <class T>
-T quat_cost(const T* x, const T* u, const double* xref, const double* uref, const double* qd, const double* rd)
+T quat_cost(const T* x, const T* u, const double* xref, const double* uref, const double* Q, const double* R)
 {
     T G[4][3];
     quat_G(x, G);
-    T total = lift(x[0], 0.0);
+    T e[12], du[4];
     for (int j = 0; j < 3; ++j) {
-        T e = G[0][j] * (x[0] - xref[0]);
-        for (int i = 1; i < 4; ++i) e = e + G[i][j] * (x[i] - xref[i]);
-        total = total + (0.5 * qd[j]) * (e * e);
+        e[j] = G[0][j] * (x[0] - xref[0]);
+        for (int i = 1; i < 4; ++i) e[j] = e[j] + G[i][j] * (x[i] - xref[i]);
     }
-    for (int j = 0; j < 9; ++j) {
-        const T e = x[4 + j] - xref[4 + j];
-        total = total + (0.5 * qd[3 + j]) * (e * e);
-    }
-    for (int j = 0; j < 4; ++j) {
-        const T e = u[j] - uref[j];
-        total = total + (0.5 * rd[j]) * (e * e);
-    }
-    return total;
+    for (int j = 0; j < 9; ++j) e[3 + j] = x[4 + j] - xref[4 + j];
+    for (int j = 0; j < 4; ++j) du[j] = u[j] - uref[j];
+    return half_form<T, 12>(Q, e) + half_form<T, 4>(R, du);
 }
 
 // ---------------------------------------------------------------- Jacobians by forward mode
@@ -337,12 +343,12 @@ void oracle_quad_quat_G(const double* x, double* G)
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 3; ++j) G[i * 3 + j] = g[i][j];
 }
-/* w = [xref(13), uref(4), qdiag(12), rdiag(4)] */
+/* w = [xref(13), uref(4), Q(12 x 12), R(4 x 4)] */
 void oracle_quad_quat_cost(const double* w, const double* x, const double* u, double* c)
 {
-    *c = quat_cost<double>(x, u, w, w + 13, w + 17, w + 29);
+    *c = quat_cost<double>(x, u, w, w + 13, w + 17, w + 161);
 }
-/* l_x [13], l_u [4], l_xx [13 x 13] (l_ux = 0, l_uu = diag(rd)) */
+/* l_x [13], l_u [4], l_xx [13 x 13] (l_ux = 0, l_uu = (R + R')/2) */
 void oracle_quad_quat_cost_derivs(const double* w, const double* x, const double* u, double* lx, double* lu, double* lxx)
 {
     typedef Dual<double, 13> D1;
@@ -364,12 +370,16 @@ void oracle_quad_quat_cost_derivs(const double* w, const double* x, const double
             for (int t = 0; t < 13; ++t) us[i].d[k].d[t] = 0.0;
         }
     }
-    const D2 c = quat_cost<D2>(xs, us, w, w + 13, w + 17, w + 29);
+    const D2 c = quat_cost<D2>(xs, us, w, w + 13, w + 17, w + 161);
     for (int i = 0; i < 13; ++i) {
         lx[i] = c.d[i].v;
         for (int j = 0; j < 13; ++j) lxx[i * 13 + j] = c.d[i].d[j];
     }
-    for (int j = 0; j < 4; ++j) lu[j] = w[29 + j] * (u[j] - w[13 + j]);
+    const double* Rm = w + 161;
+    for (int j = 0; j < 4; ++j) {
+        lu[j] = 0.0;
+        for (int k = 0; k < 4; ++k) lu[j] += 0.5 * (Rm[j * 4 + k] + Rm[k * 4 + j]) * (u[k] - w[13 + k]);
+    }
 }
 
 }  /* extern "C" */

@@ -120,7 +120,8 @@ def make_plant(spec):
     cls = dict(acrobot="Acrobot2DModel", quad_ea="QuadrotorEAModel", quad_quat="QuadrotorQuatModel")[kind]
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        p = M[cls](Q=spec["Q"], Qf=spec["Qf"], R=spec["R"], dt=spec["dt"], N=spec["N"])
+        p = M[cls](Q=spec["Q"], Qf=spec["Qf"], R=spec["R"], dt=spec["dt"], N=spec["N"],
+                   integration=spec.get("integration", "RK4"))
     p.set_references(spec["xref"], spec["uref"])
     return p
 
@@ -131,9 +132,8 @@ def par_block(spec):
         return np.asarray(make_user_plant(spec).p, dtype=np.float64)
     if spec["model"] == "car":
         return co.pack_car(spec["r"], spec["v_target"])
-    if spec["model"] == "quad_quat":
-        return co.pack_quat(spec["dt"], spec["Q"], spec["Qf"], spec["R"], spec["xref"], spec["uref"])
-    return co.pack_quadratic(spec["dt"], spec["Q"], spec["Qf"], spec["R"], spec["xref"], spec["uref"])
+    return co.pack_quadratic(spec["dt"], spec["Q"], spec["Qf"], spec["R"], spec["xref"], spec["uref"],
+                             euler=spec.get("integration", "RK4") != "RK4")
 
 
 def run_reference(plant, sp, x0, u_init):
@@ -270,6 +270,8 @@ def run_cases(name, spec, sp, X0, U0, pool, check_stable=True, extra=None):
         out[k] = np.array([r[k] for r in res], dtype=np.float64)
     for k in ("iters", "status", "regu_rounds", "n_eig", "n_complex", "stable", "dstable"):
         out[k] = np.array([r[k] for r in res], dtype=np.int32)
+    if spec["model"] not in ("car", "user"):
+        out["model_N"] = spec["N"]        # the horizon the PLANT was built with: its cost_trj sums over that one
     if extra:
         out.update(extra)
     os.makedirs(OUT, exist_ok=True)
@@ -458,6 +460,39 @@ def gen_baseline_horizons(pool):
     run_cases("car_circle_N60", CAR, dict(CAR_SP, N=60), X0, rng.standard_normal((B, 59, 2)) * 1e-4, pool)
 
 
+def gen_variants(pool):
+    """What the plants' constructors accept beyond the notebooks' settings: `integration` other than "RK4" (one Euler
+    step, acrobot.py:83-86), weight matrices that are neither diagonal nor symmetric (Quadrotor_Quat.py:152 takes any
+    Q), and a plant built with a shorter horizon than the solver runs (cost_trj sums over the plant's, acrobot.py:139).
+    Starts near the goal / near hover, so that the solves are reproducible."""
+    rng = np.random.default_rng(44)
+    B = 16
+    sp = dict(N=30, max_iter=20, max_ls=10, d_tol=5e-4)
+    # acrobot, Euler, from near the upright goal
+    X0 = np.array([np.pi, 0, 0, 0]) + 0.3 * rng.standard_normal((B, 4))
+    spa = dict(N=40, max_iter=20, max_ls=10, d_tol=1e-3)
+    run_cases("acrobot_euler_N40", dict(acrobot_spec(40), integration="Euler"), spa, X0,
+              0.5 * rng.standard_normal((B, 39, 1)), pool)
+    # plant horizon 25, solver horizon 40
+    run_cases("acrobot_modelN25_N40", acrobot_spec(25), spa, X0, 0.5 * rng.standard_normal((B, 39, 1)), pool)
+    # quadrotors near hover
+    Xe = np.zeros((B, 12)); Xe[:, 2] = 0.8; Xe[:, 3:6] = 0.2 * rng.standard_normal((B, 3))
+    Xe[:, :2] = 0.2 * rng.standard_normal((B, 2))
+    Ue = 1.9 + 0.5 * rng.standard_normal((B, 29, 4))
+    run_cases("quad_ea_euler_N30", dict(ea_spec(30), integration="Euler"), sp, Xe, Ue, pool)
+    Xq = np.zeros((B, 13)); Xq[:, 6] = 0.8; Xq[:, 4:6] = 0.2 * rng.standard_normal((B, 2))
+    for b in range(B):
+        Xq[b, :4] = euler_zyx_to_quat(0.2 * rng.standard_normal(3))
+    run_cases("quad_quat_euler_N30", dict(quat_spec(30), integration="Euler"), sp, Xq, Ue, pool)
+    # full weights: the notebook's diagonals plus couplings that are not symmetric
+    spec = quat_spec(30)
+    C = rng.standard_normal((12, 12))
+    spec["Q"] = spec["Q"] + 0.3 * C
+    spec["Qf"] = spec["Qf"] + 3.0 * rng.standard_normal((12, 12))
+    spec["R"] = spec["R"] + 0.004 * rng.standard_normal((4, 4))
+    run_cases("quad_quat_fullw_N30", spec, sp, Xq, Ue, pool)
+
+
 def gen_units(pool):
     """Pure functions of the reference solver on random blocks (iLQRController.py:125-147, model.py:45-53)."""
     from control.iLQRController import iLQR
@@ -522,7 +557,7 @@ def gen_quat_utils(pool):
 
 
 GENS = dict(quat_utils=gen_quat_utils, user_rover=gen_user_rover, car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
-            acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat, baseline=gen_baseline_horizons, units=gen_units)
+            acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat, baseline=gen_baseline_horizons, variants=gen_variants, units=gen_units)
 
 
 def main():

@@ -102,3 +102,11 @@ def min_compared(name, g):
     if name in STATUS_CLASS_FIXTURES:
         return STATUS_CLASS_FIXTURES[name]
     return (len(g["iters"]) + 1) // 2
+
+
+def cost_horizon(g):
+    """Knot points the fixture's plant sums its trajectory cost over (0: the solver's horizon).  Fixtures of the acrobot
+    and the quadrotors record the horizon their plant was built with (`model_N`)."""
+    if "model_N" in getattr(g, "files", g):
+        return 0 if int(g["model_N"]) == int(g["N"]) else int(g["model_N"])
+    return 0

@@ -38,17 +38,18 @@ def test_header_functions_are_exported(L):
 def test_model_info(L):
     from ilqr_amd import _lib
     assert _lib.model_info(0) == (5, 2, 5, 2)
-    assert _lib.model_info(1) == (4, 1, 4, 1 + 16 + 16 + 1 + 4 + 1)
-    assert _lib.model_info(2) == (12, 4, 12, 1 + 144 + 144 + 16 + 12 + 4)
-    assert _lib.model_info(3) == (13, 4, 12, 46)
+    # [dt, Q, Qf, R, xref, uref, euler]
+    assert _lib.model_info(1) == (4, 1, 4, 1 + 16 + 16 + 1 + 4 + 1 + 1)
+    assert _lib.model_info(2) == (12, 4, 12, 1 + 144 + 144 + 16 + 12 + 4 + 1)
+    assert _lib.model_info(3) == (13, 4, 12, 1 + 144 + 144 + 16 + 13 + 4 + 1)
     assert L.ilqr_model_info(9, None, None, None, None) == -1
     assert b"model" in L.ilqr_last_error()
 
 
 def test_struct_layout_matches_header():
     from ilqr_amd import _lib
-    assert C.sizeof(_lib.Problem) == 56     # 4 int32, double, 2 int64, pointer, 2 int32
-    assert C.sizeof(_lib.Outputs) == 13 * 8
+    assert C.sizeof(_lib.Problem) == 64     # 4 int32, double, 2 int64, pointer, 4 int32
+    assert C.sizeof(_lib.Outputs) == 14 * 8
     assert C.sizeof(_lib.Timing) == 6 * 8 + 6 * 4 + 2 * 4
 
 
@@ -65,7 +66,8 @@ def test_argument_validation_and_workspace(L):
     need = 8 * 1024 * (S * m + S * m * n + 40 * nx + S * m)
     assert L.ilqr_workspace_bytes(C.byref(p)) >= need
     assert L.ilqr_workspace_bytes(C.byref(prob(N=1))) == 0
-    for bad in (prob(N=1), prob(B=0), prob(stride=8), prob(model_id=7), prob(params=None)):
+    for bad in (prob(N=1), prob(B=0), prob(stride=8), prob(model_id=7), prob(params=None), prob(cost_N=41),
+                prob(cost_N=-1)):
         assert L.ilqr_solve_batch(C.byref(bad), fake, fake, fake, None, fake, 1 << 40, None) == -1
     assert L.ilqr_solve_batch(C.byref(p), None, fake, fake, None, fake, 1 << 40, None) == -1
     assert L.ilqr_solve_batch(C.byref(p), fake, fake, fake, None, fake, 16, None) == -2

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, load_golden
-from helpers import compare_to_golden, min_compared, model_key, rel_traj, tolerance
+from helpers import compare_to_golden, cost_horizon, min_compared, model_key, rel_traj, tolerance
 
 pytestmark = pytest.mark.gpu
 MID = dict(car=0, acrobot=1, quad_ea=2, quad_quat=3)
@@ -23,7 +23,7 @@ def _solve(g_or_cfg, x0, u0, trace=64, flags=0):
     from ilqr_amd.batch import BatchSolver
     c = g_or_cfg
     s = BatchSolver(MID[str(c["model"])], c["par"], int(c["N"]), int(c["max_iter"]), int(c["max_ls"]),
-                    float(c["d_tol"]), trace_len=trace, flags=flags)
+                    float(c["d_tol"]), trace_len=trace, flags=flags, cost_N=cost_horizon(c))
     r = s.solve(x0, u0)
     cp = lambda t: t.cpu().numpy()
     return dict(x=cp(r.x), u=cp(r.u), J=cp(r.J), J0=cp(r.J0), iters=cp(r.iters), status=cp(r.status),
@@ -120,12 +120,30 @@ def test_hip_matches_checker_on_seeded_batch(torch_gpu, oracle, kind, B):
     assert abs(r["iters"].mean() - i["iters"].mean()) <= 0.15 * i["iters"].mean() + 0.5
 
 
-@pytest.mark.parametrize("kind", ["car", "acrobot", "quad_ea", "quad_quat"])
-def test_model_eval_matches_checker(torch_gpu, oracle, kind):
+def _variant(oracle, kind, variant):
+    """The plant configurations of _cfg, or the same plants with what their constructors also accept: Euler integration
+    (acrobot.py:83-86) and, for the quaternion plant, weights that are neither diagonal nor symmetric."""
+    c = _cfg(oracle, kind)
+    if variant == "notebook":
+        return c
+    rng = np.random.default_rng(17)
+    par = np.array(c["par"], copy=True)
+    par[-1] = 1.0                                     # euler
+    if kind == "quad_quat":
+        par[1:145] += 0.3 * rng.standard_normal(144)      # Q
+        par[145:289] += 3.0 * rng.standard_normal(144)    # Qf
+        par[289:305] += 0.004 * rng.standard_normal(16)   # R
+    return dict(c, par=par)
+
+
+@pytest.mark.parametrize("kind,variant", [("car", "notebook"), ("acrobot", "notebook"), ("quad_ea", "notebook"),
+                                          ("quad_quat", "notebook"), ("acrobot", "euler"), ("quad_ea", "euler"),
+                                          ("quad_quat", "euler_full_weights")])
+def test_model_eval_matches_checker(torch_gpu, oracle, kind, variant):
     """discrete_dynamics, _cost_stage, _cost_final, stage, final at random points (fp64, rtol 1e-10)."""
     from ilqr_amd.batch import BatchSolver
     rng = np.random.default_rng(11)
-    c = _cfg(oracle, kind)
+    c = _variant(oracle, kind, variant)
     B = 128
     x0, u0 = _inputs(kind, rng, B, 3)
     xs = x0 + 0.1 * rng.standard_normal(x0.shape)
@@ -259,8 +277,19 @@ def test_model_interface_single_point(torch_gpu, oracle):
     assert np.isclose(ac._cost_stage(xa, ua, ac.xref, ac.uref), ea["cs"], rtol=1e-12)
     Q = np.diag([10.0] * 6 + [1.0] * 6)
     qq = QuadrotorQuatModel(Q, Q, np.eye(4) * 0.02, 0.01, 10)
-    with pytest.raises(NotImplementedError):
-        QuadrotorQuatModel(np.ones((12, 12)), Q, np.eye(4), 0.01, 10)
+    # any Q, Qf, R (Quadrotor_Quat.py:152), and `integration` other than "RK4" = Euler (:123-126)
+    rng = np.random.default_rng(3)
+    Qn, Qfn, Rn = Q + 0.3 * rng.standard_normal((12, 12)), Q + rng.standard_normal((12, 12)), 0.02 * np.eye(4) + 0.004 * rng.standard_normal((4, 4))
+    qe = QuadrotorQuatModel(Qn, Qfn, Rn, 0.01, 10, integration="Euler")
+    xr = np.zeros(13); xr[0] = 1.0; xr[6] = 1.0
+    qe.set_references(xr, np.zeros(4))
+    parq = oracle.pack_quadratic(0.01, Qn, Qfn, Rn, xr, np.zeros(4), euler=True)
+    xq = 0.3 * rng.standard_normal(13); xq[:4] = [0.9, 0.1, -0.2, 0.3]
+    uq = 1.9 + 0.3 * rng.standard_normal(4)
+    eq = oracle.eval_point("quad_quat", parq, xq, uq)
+    assert np.allclose(qe.discrete_dynamics(xq, uq), eq["xn"], rtol=1e-12)
+    assert np.isclose(qe._cost_stage(xq, uq, qe.xref, qe.uref), eq["cs"], rtol=1e-11)
+    assert np.isclose(qe._cost_final(xq, qe.xref), eq["cf"], rtol=1e-11)
     s = np.zeros(13); s[0] = 1; r = np.zeros(13); r[0] = 1; r[4] = 0.5
     assert qq.CalcDifferentialState(s, r).shape == (12,)
 
@@ -578,3 +607,52 @@ def test_lapack_eigvals_flag_reproduces_the_reference_at_long_horizons(torch_gpu
         n = compare_to_golden(g, r["x"], r["u"], r["J"], r["iters"], r["status"], r["ls"], r["acc"], r["regu"], J0=r["J0"],
                               label=name + " (LAPACK's rule)")
         assert n >= min_compared(name, g)
+
+
+def test_line_search_counters_and_plant_horizon(torch_gpu):
+    """iLQRController.py:57-58, :69-74: after run_ilqr, num_ls_success / num_ls_fails describe the last iteration that
+    reached the line search (a call in which none did leaves them alone).  acrobot.py:139: the plant's cost_trj sums over
+    the horizon the PLANT was built with; fixture acrobot_modelN25_N40 is the reference run that way."""
+    from ilqr_amd import Acrobot2DModel, CarModel, iLQR
+    g = load_golden("car_box256")
+    ctl = iLQR(CarModel(2, 2), N=40, max_iter=50, max_linesearch_iters=20)
+    n = 64
+    u = g["u_init"][:n].copy()
+    ctl.run_ilqr(g["x0"][:n], u)
+    it = g["iters"][:n]
+    searched = g["ls_evals"][:n] > 0
+    for b in range(n):
+        if not g["dstable"][b]:
+            continue
+        ks = np.nonzero(searched[b, :it[b]])[0]
+        want = (0, 0) if len(ks) == 0 else (int(g["accepted"][b, ks[-1]]), int(not g["accepted"][b, ks[-1]]))
+        assert (int(ctl.num_ls_success[b]), int(ctl.num_ls_fails[b])) == want, b
+    # single trajectory, no trace requested
+    one = iLQR(CarModel(2, 2), N=40, max_iter=50, max_linesearch_iters=20)
+    r = load_golden("car_readme")
+    one.run_ilqr(r["x0"][0], r["u_init"][0].copy())
+    assert (one.num_ls_success, one.num_ls_fails) == (1, 0)
+    m1 = load_golden("car_maxls1")           # evaluation number max_ls is never accepted (:66-67)
+    one1 = iLQR(CarModel(2, 2), N=40, max_iter=int(m1["max_iter"]), max_linesearch_iters=1)
+    one1.run_ilqr(m1["x0"][0], m1["u_init"][0].copy())
+    assert (one1.num_ls_success, one1.num_ls_fails) == (0, 1)
+    # plant horizon 25, solver horizon 40
+    h = load_golden("acrobot_modelN25_N40")
+    ac = Acrobot2DModel(np.diag([1, 1, .1, .1]), 100 * np.eye(4), np.array([[0.01]]), 0.05, 25)
+    ac.set_references(np.array([np.pi, 0, 0, 0.0]), np.zeros(1))
+    c = iLQR(ac, N=40, max_iter=int(h["max_iter"]), max_linesearch_iters=int(h["max_ls"]), d_tol=float(h["d_tol"]))
+    uu = h["u_init"].copy()
+    xx, _ = c.run_ilqr(h["x0"], uu)
+    ok = h["dstable"] == 1
+    assert ok.sum() >= 8
+    assert np.array_equal(c.info.iters.cpu().numpy()[ok], h["iters"][ok])
+    st = h["stable"] == 1      # (also reproduces its cost and trajectory to 1e-8 under a 1e-14 perturbation)
+    assert st.sum() >= 8
+    assert np.allclose(c.info.J.cpu().numpy()[st], h["J_last"][st], rtol=1e-6, equal_nan=True)
+    assert np.allclose(xx[st], h["x"][st], rtol=1e-6, atol=1e-7, equal_nan=True)
+    # cost_trj of the plant itself: 24 stage costs and the final cost of the last state
+    J = ac.cost_trj(h["x"][0], h["u"][0])
+    want = sum(ac._cost_stage(h["x"][0][k], h["u"][0][k]) for k in range(24)) + ac._cost_final(h["x"][0][-1])
+    assert np.isclose(J, want, rtol=1e-12)
+    with pytest.raises(IndexError):      # the reference indexes past the trajectory
+        iLQR(Acrobot2DModel(ac.Q, ac.Qf, ac.R, 0.05, 50), N=40, max_iter=2).run_ilqr(h["x0"][0], h["u_init"][0].copy())

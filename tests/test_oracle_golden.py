@@ -4,14 +4,14 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, load_golden
-from helpers import compare_to_golden, min_compared, model_key
+from helpers import compare_to_golden, cost_horizon, min_compared, model_key
 
 
 @pytest.mark.parametrize("name", golden_names())
 def test_oracle_matches_reference_golden(oracle, name):
     g = load_golden(name)
     r = oracle.solve_batch(model_key(g), g["par"], int(g["N"]), int(g["max_iter"]), int(g["max_ls"]),
-                           float(g["d_tol"]), g["x0"], g["u_init"])
+                           float(g["d_tol"]), g["x0"], g["u_init"], cost_N=cost_horizon(g))
     i = r["info"]
     n = compare_to_golden(g, r["x"], r["u"], i["J_last"], i["iters"], i["status"], i["ls_evals"], i["accepted"],
                           i["regu_rounds"], J0=i["J0"], label=name)

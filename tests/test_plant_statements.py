@@ -21,8 +21,10 @@ def test_plant_statements_agree_numerically():
         assert p.quad_ea_xdot(x12, u4) == o.quad_ea_xdot(x12, u4)
         x13 = list(rng.standard_normal(13))
         assert p.quad_quat_xdot(x13, u4) == o.quad_quat_xdot(x13, u4)
-        xr, qd, rd = list(rng.standard_normal(13)), list(rng.uniform(0.1, 2, 12)), list(rng.uniform(0.1, 2, 4))
-        assert p.quat_cost(x13, u4, xr, u4, qd, rd) == o.quat_cost(x13, u4, xr, u4, qd, rd)
+        xr, Qw, Rw = list(rng.standard_normal(13)), rng.standard_normal((12, 12)).tolist(), rng.standard_normal((4, 4)).tolist()
+        ur = list(rng.standard_normal(4))
+        assert p.quat_cost(x13, u4, xr, ur, Qw, Rw) == o.quat_cost(x13, u4, xr, ur, Qw, Rw)
+        assert p.quat_state_error(x13, xr) == o.quat_state_error(x13, xr)
         assert p.rk4_step(p.acrobot_xdot, x4, u1, 0.05) == o.rk4_step(o.acrobot_xdot, x4, u1, 0.05)
 
 
@@ -51,3 +53,36 @@ def test_hand_written_checker_plants_agree_with_the_numpy_statement(oracle):
             fu = np.column_stack([(step(x, u + h * np.eye(nu)[j]) - step(x, u - h * np.eye(nu)[j])) / (2 * h) for j in range(nu)])
             assert np.allclose(e["f_x"], fx, rtol=1e-6, atol=1e-7), kind
             assert np.allclose(e["f_u"], fu, rtol=1e-6, atol=1e-7), kind
+
+
+def test_quaternion_cost_with_full_weights(oracle):
+    """Quadrotor_Quat.py:150-175 takes any Q, Qf [12 x 12] and R [4 x 4].  The checker's cost (hand-written, AD) against
+    the NumPy statement of 0.5 e'Qe + 0.5 du'R du for weights that are neither diagonal nor symmetric: values, and the
+    13-dim gradient and Hessian against central differences of the NumPy value."""
+    from oracle import models_numpy as o
+    rng = np.random.default_rng(8)
+    Q = rng.standard_normal((12, 12)); Qf = rng.standard_normal((12, 12)); R = rng.standard_normal((4, 4))
+    xr = rng.standard_normal(13); ur = rng.standard_normal(4)
+    par = oracle.pack_quadratic(0.01, Q, Qf, R, xr, ur)
+    assert par.size == 323
+    cost = lambda xv, uv: o.quat_cost(list(xv), list(uv), list(xr), list(ur), Q.tolist(), R.tolist())
+    for _ in range(5):
+        x = 0.5 * rng.standard_normal(13); x[:4] = [1, 0, 0, 0] + 0.3 * rng.standard_normal(4)
+        u = rng.standard_normal(4)
+        e = oracle.eval_point("quad_quat", par, x, u)
+        assert np.isclose(e["cs"], cost(x, u), rtol=1e-12, atol=1e-13)
+        assert np.isclose(e["cf"], o.quat_cost(list(x), list(u), list(xr), list(ur), Qf.tolist(), R.tolist(), with_action=False),
+                          rtol=1e-12, atol=1e-13)
+        h = 1e-5
+        I = np.eye(13)
+        g = np.array([(cost(x + h * I[j], u) - cost(x - h * I[j], u)) / (2 * h) for j in range(13)])
+        gu = np.array([(cost(x, u + h * np.eye(4)[j]) - cost(x, u - h * np.eye(4)[j])) / (2 * h) for j in range(4)])
+        # (eval_point returns the cost derivatives in the 13-dim state; the solver projects them with G afterwards)
+        assert np.allclose(e["l_x"], g, rtol=1e-6, atol=1e-7)
+        assert np.allclose(e["l_u"], gu, rtol=1e-6, atol=1e-7)
+        assert np.allclose(e["l_uu"], 0.5 * (R + R.T), rtol=1e-12)
+        h2 = 1e-4
+        H = np.array([[(cost(x + h2 * I[i] + h2 * I[j], u) - cost(x + h2 * I[i] - h2 * I[j], u)
+                        - cost(x - h2 * I[i] + h2 * I[j], u) + cost(x - h2 * I[i] - h2 * I[j], u)) / (4 * h2 * h2)
+                       for j in range(13)] for i in range(13)])
+        assert np.allclose(e["l_xx"], H, rtol=1e-4, atol=1e-5)

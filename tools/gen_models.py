@@ -175,32 +175,29 @@ def gen_quad_quat():
         "quad_quat", mn.quad_quat_xdot, 13, 4,
         "Quaternion quadrotor: reference control/models/Quadrotor_Quat.py:63-111 with "
         "maths/casadi_quaternions.py:5-34, continuous-time Jacobians (Quadrotor_Quat.py:130-131), "
-        "attitude Jacobian and error-state cost with its derivatives (Quadrotor_Quat.py:142-175). "
-        "w = [xref(13), uref(4), qdiag(12), rdiag(4)].")
-    xr = sp.symbols("xr0:13", real=True)
-    ur = sp.symbols("ur0:4", real=True)
-    qd = sp.symbols("qd0:12", real=True)
-    rd = sp.symbols("rd0:4", real=True)
-    w = list(xr) + list(ur) + list(qd) + list(rd)
+        "attitude Jacobian and the attitude part of the error state with its derivatives "
+        "(Quadrotor_Quat.py:142-150).")
     G = sp.Matrix(mn.quat_attitude_jacobian(list(xs[:4])))
     s, ops["G"] = emit_function("quad_quat_gen_G", [("x", xs)], [("G", G)],
                                 "attitude Jacobian G(q) [4x3] of the normalised quaternion "
                                 "(casadi_quaternions.py:22); the 13x12 state Jacobian is blkdiag(G, I9)")
     out += s
-    c = mn.quat_cost(list(xs), list(us), list(xr), list(ur), list(qd), list(rd))
-    ins = [("w", w), ("x", xs), ("u", us)]
-    s, ops["cost"] = emit_function("quad_quat_gen_cost", ins, [("c", [c])],
-                                   "0.5 e'Qe + 0.5 du'R du, e = Gx(x)'(x - xref) (Quadrotor_Quat.py:150-152)")
+    # The error state e = Gx(x)'(x - xref) is nonlinear in x only through its first three entries,
+    # a = G(q)'(q - qref); the other nine are differences.  The cost 0.5 e'Qe + 0.5 du'R du and its derivatives for
+    # ANY Q, R are assembled from a, da/dq and the three Hessians of a by the caller (models.hpp), so that the weights
+    # stay run-time parameters.
+    qs = list(xs[:4])
+    qr = sp.symbols("qr0:4", real=True)
+    a = sp.Matrix(mn.quat_state_error(list(xs), list(qr) + [0] * 9)[:3])
+    s, ops["err"] = emit_function("quad_quat_gen_err", [("qr", qr), ("x", xs)], [("a", a)],
+                                  "a[3] = G(q)'(q - qref): the attitude entries of state_err (Quadrotor_Quat.py:150)")
     out += s
-    # only the quaternion block of the state Hessian is non-trivial, but the
-    # reference differentiates the whole 13-vector, so emit dense 13x13.
-    cx = sp.Matrix([c]).jacobian(xs)
-    cu = sp.Matrix([c]).jacobian(us)
-    s, ops["cost_derivs"] = emit_function(
-        "quad_quat_gen_cost_derivs", ins,
-        [("l_x", cx), ("l_u", cu), ("l_xx", cx.jacobian(xs))],
-        "l_x[13], l_u[4], l_xx[13x13] of the cost above (Quadrotor_Quat.py:158-163); "
-        "l_ux = 0 and l_uu = diag(rd) are written by the caller")
+    Ja = a.jacobian(qs)
+    Ha = [sp.hessian(a[i], qs) for i in range(3)]
+    s, ops["err_derivs"] = emit_function(
+        "quad_quat_gen_err_derivs", [("qr", qr), ("x", xs)],
+        [("a", a), ("Ja", Ja), ("Ha", [Ha[i][r, c] for i in range(3) for r in range(4) for c in range(4)])],
+        "a[3], Ja = da/dq [3x4], Ha[i] = d2 a_i / dq2 [3][4x4]")
     out += s
     return out, ops
 
