@@ -25,7 +25,7 @@ PHASES = ("init", "backward", "forward1", "backtrack", "commit", "export")
 
 EXPORTS = ("ilqr_model_info", "ilqr_workspace_bytes", "ilqr_solve_batch", "ilqr_rollout_cost",
            "ilqr_model_eval", "ilqr_mpc_advance", "ilqr_last_timing", "ilqr_last_error", "ilqr_version",
-           "ilqr_solve_batch_static", "ilqr_eigvals_negative")
+           "ilqr_solve_batch_static", "ilqr_eigvals_negative", "ilqr_linearize_continuous")
 STATIC_WORKSPACE_BYTES = 32 << 20
 
 _dp = C.c_void_p  # device pointers travel as plain addresses
@@ -77,6 +77,8 @@ def lib(path=None):
     L.ilqr_rollout_cost.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, _dp, _dp]
     L.ilqr_model_eval.restype = C.c_int
     L.ilqr_model_eval.argtypes = [C.POINTER(Problem)] + [_dp] * 15
+    L.ilqr_linearize_continuous.restype = C.c_int
+    L.ilqr_linearize_continuous.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, _dp, _dp]
     L.ilqr_mpc_advance.restype = C.c_int
     L.ilqr_mpc_advance.argtypes = [C.POINTER(Problem), _dp, _dp, _dp]
     L.ilqr_last_timing.restype = C.c_int

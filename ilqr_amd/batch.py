@@ -225,6 +225,21 @@ class BatchSolver:
                                             *[_ptr(bufs.get(k)) for k in order], self._stream()))
         return {k: bufs[k].t().reshape((B,) + shapes[k]) for k in what}
 
+    def linearize_continuous(self, xs, us):
+        """A = d xdot/dx [B, ndx, ndx] and B = d xdot/du [B, ndx, nu] of the continuous-time dynamics at B points
+        (on the error state for the quaternion plant): the plants' _linearize_continuous."""
+        xd = self._to_dev(xs).reshape(-1, self.nx)
+        B = xd.shape[0]
+        ud = self._to_dev(us).reshape(B, self.nu)
+        n, m = self.ndx, self.nu
+        Ab = torch.empty((n * n, B), dtype=torch.float64, device=self.device)
+        Bb = torch.empty((n * m, B), dtype=torch.float64, device=self.device)
+        pr = self._problem(B, B)
+        xs_soa, us_soa = xd.t().contiguous(), ud.t().contiguous()
+        self._check(self.lib.ilqr_linearize_continuous(C.byref(pr), _ptr(xs_soa), _ptr(us_soa), _ptr(Ab), _ptr(Bb),
+                                                      self._stream()))
+        return Ab.t().reshape(B, n, n), Bb.t().reshape(B, n, m)
+
     def mpc_advance(self, x0_soa: torch.Tensor, u_soa: torch.Tensor, B: Optional[int] = None):
         """In place on SoA buffers: x0 <- f(x0, u[0]); u[:-1] <- u[1:]."""
         stride = x0_soa.shape[-1]

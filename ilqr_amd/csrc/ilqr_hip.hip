@@ -109,6 +109,27 @@ __global__ __launch_bounds__(WG) void eval_kernel(Dev a, const double* __restric
     }
 }
 
+// A = d xdot/dx, B = d xdot/du at one point per lane (on the error state for the quaternion plant)
+template <class M>
+__global__ __launch_bounds__(WG) void lincont_kernel(Dev a, const double* __restrict__ xs, const double* __restrict__ us,
+                                                     double* __restrict__ A, double* __restrict__ B)
+{
+    if constexpr (M::HAS_CONTINUOUS) {
+        constexpr int n = M::NDX, m = M::NU, nx = M::NX;
+        const long b = (long)blockIdx.x * WG + threadIdx.x;
+        if (b >= a.p.B) return;
+        const long st = a.p.stride;
+        double x[nx], u[m], Ac[n * n], Bc[n * m];
+        for (int i = 0; i < nx; ++i) x[i] = xs[(long)i * st + b];
+        for (int i = 0; i < m; ++i) u[i] = us[(long)i * st + b];
+        M::linearize_continuous(par_of<M>(a.p, b).get(), x, u, Ac, Bc);
+        if (A)
+            for (int i = 0; i < n * n; ++i) A[(long)i * st + b] = Ac[i];
+        if (B)
+            for (int i = 0; i < n * m; ++i) B[(long)i * st + b] = Bc[i];
+    }
+}
+
 // x0 <- f(x0, u[0]); u[k] <- u[k+1] for k < S-1
 template <class M>
 __global__ __launch_bounds__(WG) void mpc_advance_kernel(Dev a, double* __restrict__ x0, double* __restrict__ u)
@@ -522,6 +543,27 @@ int ilqr_model_eval(const ilqr_problem* p, const double* xs, const double* us, d
     return dispatch(p->model_id, [&](auto M) {
         using Mt = decltype(M);
         hipLaunchKernelGGL(eval_kernel<Mt>, grid, block, 0, s, a, xs, us, o);
+        HIP_TRY(hipGetLastError());
+        return (int)ILQR_OK;
+    });
+}
+
+int ilqr_linearize_continuous(const ilqr_problem* p, const double* xs, const double* us, double* A, double* B, void* stream)
+{
+    ModelDims d;
+    int rc = check_problem(p, d);
+    if (rc) return rc;
+    if (!xs || !us) return fail(ILQR_E_BADARG, "xs and us must be non-NULL");
+    Dev a;
+    a.p = *p;
+    memset(&a.o, 0, sizeof(a.o));
+    dim3 grid((unsigned)((p->B + WG - 1) / WG)), block(WG);
+    hipStream_t s = (hipStream_t)stream;
+    return dispatch(p->model_id, [&](auto M) {
+        using Mt = decltype(M);
+        if (!Mt::HAS_CONTINUOUS)
+            return fail(ILQR_E_BADARG, "this plant states its discrete step only (no continuous-time dynamics to linearise)");
+        hipLaunchKernelGGL(lincont_kernel<Mt>, grid, block, 0, s, a, xs, us, A, B);
         HIP_TRY(hipGetLastError());
         return (int)ILQR_OK;
     });

@@ -41,6 +41,7 @@ struct CarModel {
     static constexpr int NX = 5, NU = 2, NDX = 5, NPAR = 2;
     static constexpr bool UNROLL = true;
     static constexpr bool TEAM_BACKWARD = false;
+    static constexpr bool HAS_CONTINUOUS = false;     // car.py states the step itself (x + xdot dt folded in)
     // second argument of the backward kernel's __launch_bounds__ (minimum waves per SIMD the register allocator must
     // leave room for).  1 = no cap below the 512 registers of a lane: the kernel comes out at 242 VGPRs, no AGPRs, no
     // scratch, i.e. two resident waves per SIMD; asking for 3 or 4 makes the compiler spill ~1 KB per lane (measured
@@ -90,6 +91,7 @@ struct UserModel {
     static constexpr int NX = USER_NX, NU = USER_NU, NDX = USER_NX, NPAR = USER_NP;
     static constexpr bool UNROLL = true;
     static constexpr bool TEAM_BACKWARD = false;
+    static constexpr bool HAS_CONTINUOUS = false;
     static constexpr int BACKWARD_WAVES = 1;
     static constexpr long TAIL_COUNT = 16384;
     static_assert(NX + NU <= 8, "the lane-per-trajectory backward stage keeps every matrix in registers");
@@ -257,6 +259,13 @@ struct QuadraticRK4Model {
     static constexpr int NX = NX_, NU = NU_, NDX = NX_;
     // 12 states + 4 controls: the backward pass runs with 16 lanes per trajectory (team_backward.hpp)
     static constexpr bool TEAM_BACKWARD = (NX_ == 12 && NU_ == 4);
+    static constexpr bool HAS_CONTINUOUS = true;
+    // _linearize_continuous (acrobot.py:148-150, Quadrotor_EA.py:206-208): A = d xdot/dx, B = d xdot/du
+    __device__ static void linearize_continuous(const double*, const double* x, const double* u, double* A, double* B)
+    {
+        double f[NX];
+        XDOTJAC(x, u, f, A, B);
+    }
     // one column (or any combination of columns) of [d x_next/dx, d x_next/du]
     __device__ static void dynamics_jvp(double dt, bool eul, const double* x, const double* u, const double* vx,
                                         const double* vu, double* dxn)
@@ -337,6 +346,7 @@ struct QuadQuatModel {
     static constexpr int NX = 13, NU = 4, NDX = 12, NPAR = 1 + 144 + 144 + 16 + 13 + 4 + 1;
     static constexpr bool UNROLL = false;
     static constexpr bool TEAM_BACKWARD = true;      // 16 lanes per trajectory (team_backward.hpp)
+    static constexpr bool HAS_CONTINUOUS = true;
     static constexpr int BACKWARD_WAVES = 1;
     static constexpr long TAIL_COUNT = 8192;
     __device__ static const double* Qm(const double* p) { return p + 1; }
@@ -493,6 +503,16 @@ struct QuadQuatModel {
             proj_right<12>(G, T, fx);              // G' A G
             projT_left<4>(G, B, fu);               // G' B
         }
+    }
+    // _linearize_continuous (Quadrotor_Quat.py:240-246): G' A G [12x12], G' B [12x4] of the continuous dynamics
+    __device__ static void linearize_continuous(const double*, const double* x, const double* u, double* Ac, double* Bc)
+    {
+        double G[12], f[13], A[169], B[52], T[12 * 13];
+        quad_quat_gen_G(x, G);
+        quad_quat_gen_xdot_jac(x, u, f, A, B);
+        projT_left<13>(G, A, T);
+        proj_right<12>(G, T, Ac);
+        projT_left<4>(G, B, Bc);
     }
     // Quadrotor_Quat.py:259-265
     __device__ static void final(const double* par, const double* x, double* Vx, double* Vxx)

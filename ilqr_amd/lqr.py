@@ -4,8 +4,8 @@ The reference wraps Drake's DiscreteTimeLinearQuadraticRegulator / LinearQuadrat
 (control/QuadrotorControllers.py:84-128, :197-233, control/AcrobotControllers.py:68-115): linearise the plant at
 the goal, solve the Riccati equation, output u = uref - K * CalcDifferentialState(x, goal).  Here the
 linearisation comes from the plant's device code (`Model._linearize_discrete`: f_x, f_u of the integrator
-step, already on the 12-dimensional error state for the quaternion plant, Quadrotor_Quat.py:231-238) and the
-Riccati equations are SciPy's.  These are a few 12x12 solves on the host; nothing here is a hot path.
+step; `Model._linearize_continuous`: the Jacobians of xdot; both already on the 12-dimensional error state for
+the quaternion plant, Quadrotor_Quat.py:231-246) and the Riccati equations are SciPy's.  These are a few 12x12 solves on the host; nothing here is a hot path.
 """
 from __future__ import annotations
 
@@ -32,13 +32,13 @@ class LQRController:
     """u = uref - K * CalcDifferentialState(current_state, goal_state), K from the plant linearised at the goal.
 
     One class for QuadrotorEALQRController, QuadrotorQuatLQRController and AcrobotLQRController of the reference
-    (their DoCalcVectorOutput bodies); the gain is cached per goal state.  mode="discrete" only: the
-    continuous-time Jacobians of the plants are not exposed through the solver library.
+    (their DoCalcVectorOutput bodies); the gain is cached per goal state.  mode "discrete": the integrator step's
+    Jacobians and the discrete Riccati equation; any other mode: the Jacobians of xdot and the continuous one
+    (QuadrotorControllers.py:118-124, :223-229).
     """
 
     def __init__(self, model, Q=None, R=None, uref=None, mode="discrete"):
-        if mode != "discrete":
-            raise NotImplementedError("only mode='discrete' (the integrator step's Jacobians) is available")
+        self.mode = mode
         self.model = model
         self.nx, self.nu, self.ndx = model.get_dims()
         self.Q = np.asarray(model.Q if Q is None else Q, dtype=np.float64)
@@ -50,8 +50,12 @@ class LQRController:
     def gain(self, goal_state):
         goal_state = np.asarray(goal_state, dtype=np.float64)
         if self._goal is None or not np.array_equal(goal_state, self._goal):
-            A, B = self.model._linearize_discrete(goal_state, self.uref)
-            self.K, self.S = dlqr(A, B, self.Q, self.R)
+            if self.mode == "discrete":
+                A, B = self.model._linearize_discrete(goal_state, self.uref)
+                self.K, self.S = dlqr(A, B, self.Q, self.R)
+            else:
+                A, B = self.model._linearize_continuous(goal_state, self.uref)
+                self.K, self.S = lqr(A, B, self.Q, self.R)
             self._goal = goal_state.copy()
         return self.K
 

@@ -101,6 +101,15 @@ class Model:
         f_x, f_u = self._eval(ref_state, u, ("f_x", "f_u"))
         return f_x, f_u
 
+    def _linearize_continuous(self, ref_state, ref_action):
+        """(A, B) of the continuous-time dynamics at (ref_state, ref_action): acrobot.py:148-150,
+        Quadrotor_EA.py:206-208; for the quaternion plant on the error state, G'AG and G'B
+        (Quadrotor_Quat.py:240-246).  The car has none (car.py states the step)."""
+        u = np.array(np.broadcast_to(np.asarray(ref_action, dtype=np.float64), (self.nu,)))
+        x = np.asarray(ref_state, dtype=np.float64).reshape(1, self.nx)
+        A, B = self._evaluator().linearize_continuous(x, u.reshape(1, self.nu))
+        return A[0].cpu().numpy(), B[0].cpu().numpy()
+
     def final(self, x):
         """model.py:42: (V_x, V_xx)."""
         return tuple(self._eval(x, None, ("V_x", "V_xx")))

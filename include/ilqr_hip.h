@@ -205,6 +205,15 @@ int ilqr_model_eval(const ilqr_problem *p, const double *xs, const double *us, d
  * Built for w = 2..8 and 16. */
 int ilqr_eigvals_negative(int32_t w, const double *Q, int64_t B, int64_t stride, int32_t *verdict, void *stream);
 
+/* _linearize_continuous (control/models/acrobot.py:148-150, Quadrotor_EA.py:206-208, Quadrotor_Quat.py:240-246):
+ * A = d xdot/dx, B = d xdot/du of the continuous-time dynamics at one point per trajectory; for the quaternion
+ * plant on the error state, G'AG and G'B.  What the reference's LQR controllers in mode "continuous" linearise
+ * (control/QuadrotorControllers.py:123-124, :228-229).
+ *   xs [nx][stride], us [nu][stride] in; A [ndx*ndx][stride], B [ndx*nu][stride] out (row-major, either may be NULL).
+ * The car and user-defined plants state their discrete step only: ILQR_E_BADARG. */
+int ilqr_linearize_continuous(const ilqr_problem *p, const double *xs, const double *us, double *A, double *B,
+                              void *stream);
+
 /* Receding-horizon helper (control/QuadrotorControllers.py:72-76, :185-188;
  * control/AcrobotControllers.py:60-63): x0 <- discrete_dynamics(x0, u[0]) and
  * u[:-1] <- u[1:] (last row kept), in place, for B trajectories. */

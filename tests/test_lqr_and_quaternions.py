@@ -58,8 +58,8 @@ def test_lqr_controller_stabilises_the_quadrotors_about_hover(oracle):
         A, B = plant._linearize_discrete(goal, hover)
         par = plant._param_block()
         e = oracle.eval_point(kind, par, goal, hover)
-        if nx == 12:
-            assert np.allclose(A, e["f_x"], rtol=1e-10, atol=1e-12) and np.allclose(B, e["f_u"], rtol=1e-10, atol=1e-12)
+        # (for the quaternion plant both sides are on the error state: G'AG, G'B)
+        assert np.allclose(A, e["f_x"], rtol=1e-10, atol=1e-12) and np.allclose(B, e["f_u"], rtol=1e-10, atol=1e-12)
         K = ctl.gain(goal)
         assert K.shape == (4, 12) and np.abs(np.linalg.eigvals(A - B @ K)).max() < 1.0
         # closed loop on the nonlinear plant: a displaced start converges to the goal
@@ -68,5 +68,35 @@ def test_lqr_controller_stabilises_the_quadrotors_about_hover(oracle):
         for _ in range(400):
             x = plant.discrete_dynamics(x, ctl.control(x, goal))
         assert np.linalg.norm(plant.CalcDifferentialState(x, goal)) < 0.05 * d0
-    with pytest.raises(NotImplementedError):
-        LQRController(plant, mode="continuous")
+        # mode "continuous" (QuadrotorControllers.py:123-124, :228-229): Jacobians of xdot against the checker's own
+        # (hand-written dynamics, forward-mode AD), the continuous Riccati equation, and a stable closed loop
+        import ctypes as C
+        L = oracle.lib()
+        fn = getattr(L, "oracle_quad_ea_xdot_jac" if nx == 12 else "oracle_quad_quat_xdot_jac")
+        fn.restype = None
+        dp = C.POINTER(C.c_double)
+        f, Ao, Bo = np.zeros(nx), np.zeros((nx, nx)), np.zeros((nx, 4))
+        xq = goal + 0.1 * np.random.default_rng(4).standard_normal(nx)
+        fn(*(v.ctypes.data_as(dp) for v in (xq, hover, f, Ao, Bo)))
+        if nx == 13:
+            qn = xq[:4] / np.linalg.norm(xq[:4]); w_, x_, y_, z_ = qn
+            Gx = np.zeros((13, 12)); Gx[:4, :3] = [[-x_, -y_, -z_], [w_, -z_, y_], [z_, w_, -x_], [-y_, x_, w_]]
+            Gx[4:, 3:] = np.eye(9)
+            Ao, Bo = Gx.T @ Ao @ Gx, Gx.T @ Bo
+        Ac, Bc = plant._linearize_continuous(xq, hover)
+        assert Ac.shape == (12, 12) and Bc.shape == (12, 4)
+        assert np.allclose(Ac, Ao, rtol=1e-10, atol=1e-11) and np.allclose(Bc, Bo, rtol=1e-10, atol=1e-11)
+        cc = LQRController(plant, uref=hover, mode="continuous")
+        Kc = cc.gain(goal)
+        Ag, Bg = plant._linearize_continuous(goal, hover)
+        assert Kc.shape == (4, 12) and np.linalg.eigvals(Ag - Bg @ Kc).real.max() < 0.0
+        # the continuous-time gain is stiff (closed-loop poles to -450/s: outside RK4's stability region at dt = 0.01),
+        # so the closed loop is simulated with a finer step of the same plant
+        fine = cls(Q, Q, R, dt=0.002, N=20)
+        x = goal.copy(); x[(0 if nx == 12 else 4)] += 0.3
+        for _ in range(1200):
+            x = fine.discrete_dynamics(x, cc.control(x, goal))
+        assert np.linalg.norm(plant.CalcDifferentialState(x, goal)) < 0.05 * 0.3
+    from ilqr_amd import CarModel
+    with pytest.raises(RuntimeError):          # car.py states its step only
+        CarModel(2, 2)._linearize_continuous(np.zeros(5), np.zeros(2))
