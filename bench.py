@@ -266,22 +266,41 @@ def main():
             cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
             par = co.pack_car(2.0, 2.0)
             if a.check:
+                # The first c trajectories against the CPU checker.  Which solves CAN be compared one by one is decided
+                # the way the fixtures under tests/golden decide it: the checker solves them a second time with every
+                # input changed in its 14th digit, and a solve counts as reproducible if both runs take the same
+                # decisions and end within 1e-8 of each other (ill-conditioned solves amplify rounding differences
+                # until they do not; those are compared as a population by the tests, not here).
                 c = min(a.check, B)
+                rng = np.random.default_rng(99)
                 ref = co.solve_batch("car", par, N, 50, 20, 1e-3, x0_np[:c], u0_np[:c], nthreads=cores)
+                ref2 = co.solve_batch("car", par, N, 50, 20, 1e-3,
+                                      x0_np[:c] * (1.0 + 1e-14 * rng.choice([-1.0, 1.0], size=x0_np[:c].shape)),
+                                      u0_np[:c] * (1.0 + 1e-14 * rng.choice([-1.0, 1.0], size=u0_np[:c].shape)), nthreads=cores)
+                i1, i2 = ref["info"], ref2["info"]
+                scale = np.abs(ref["x"]).reshape(c, -1).max(1)
+                with np.errstate(invalid="ignore"):
+                    drift = np.abs(ref["x"] - ref2["x"]).reshape(c, -1).max(1) / scale
+                repro = ((i1["iters"] == i2["iters"]) & (i1["status"] == i2["status"]) & (i1["ls_total"] == i2["ls_total"])
+                         & (i1["regu_rounds"] == i2["regu_rounds"]) & (drift <= 1e-8))
                 it = out["iters"][:c].cpu().numpy()
-                same = it == ref["info"]["iters"]
-                calm = ref["info"]["max_abs_q"] < 1e5
+                st = out["status"][:c].cpu().numpy()
+                same = (it == i1["iters"]) & (st == i1["status"])
                 xg = x[:, :, :c].permute(2, 0, 1).cpu().numpy()
-                err = np.abs(xg - ref["x"]).reshape(c, -1).max(1) / np.abs(ref["x"]).reshape(c, -1).max(1)
-                sel = err[same & calm] if (same & calm).any() else np.array([np.nan])
-                res["parity_check"] = {"checked": int(c), "iters_identical": int(same.sum()),
-                                       "well_conditioned": int(calm.sum()),
-                                       "well_conditioned_iters_identical": int((same & calm).sum()),
-                                       "max_rel_x_err_well_conditioned": float(sel.max()),
-                                       "median_rel_x_err_well_conditioned": float(np.median(sel)),
-                                       "frac_rel_x_err_le_1e-8_well_conditioned": float((sel <= 1e-8).mean()),
-                                       "note": "well conditioned = largest |Q| entry below 1e5 in the CPU checker's solve; "
-                                               "the tests in tests/ classify by the reference's own sensitivity instead"}
+                with np.errstate(invalid="ignore"):
+                    err = np.abs(xg - ref["x"]).reshape(c, -1).max(1) / scale
+                sel = err[repro & same] if (repro & same).any() else np.array([np.nan])
+                calm = i1["max_abs_q"] < 1e5
+                res["parity_check"] = {"checked": int(c), "reproducible": int(repro.sum()),
+                                       "reproducible_same_decisions": int((repro & same).sum()),
+                                       "max_rel_x_err_reproducible": float(np.nanmax(sel)),
+                                       "median_rel_x_err_reproducible": float(np.nanmedian(sel)),
+                                       "frac_rel_x_err_le_1e-8_reproducible": float((sel <= 1e-8).mean()),
+                                       "all_same_iters_and_exit": int(same.sum()),
+                                       "max_abs_q_below_1e5": int(calm.sum()),
+                                       "max_abs_q_below_1e5_same_decisions": int((calm & same).sum()),
+                                       "note": "reproducible = the CPU checker repeats its own decisions and ends within 1e-8 when "
+                                               "its inputs are changed in the 14th digit"}
             if a.cpu_sample and world == 1:
                 c = min(a.cpu_sample, B)
                 t1 = time.perf_counter()

@@ -266,3 +266,48 @@ def test_score_of_the_ldl_rule_on_the_recorded_decisions(oracle):
     assert by_decade[0][1] / by_decade[0][0] > 0.97          # max|Q| below 1e4: nearly always
     assert 0.9 < right / n < 0.995                           # overall: a few per cent off
     assert stages_right / stages < 0.8                       # a stage's round count is often not the reference's
+
+
+def test_round_search_of_the_16_lane_kernel_on_recorded_stages(oracle):
+    """The kernels of the 12-state plants try rounds 0..16 one after the other like the reference, then double the
+    round number until the test stops failing and bisect back (csrc/team_backward.hpp).  On the stages the reference
+    recorded with more than 16 rounds (quadrotors far from hover, up to 1027 rounds: Q runs into 1e308) this measures
+    what that search finds against the one-by-one scan, under the kernels' own LDL' rule and under LAPACK's, and the
+    scan against the reference's round count.  Those stages are outside per-trajectory parity whatever the search:
+    under the LDL' rule not even the one-by-one scan ends where the reference ends."""
+    g = load_golden("eig_decisions")
+    for tag, min_same_ldl in (("ea", 0.7), ("quat", 0.9)):
+        Q0, Pm, rounds, end = g[tag + "_Q0"], g[tag + "_P"], g[tag + "_rounds"], g[tag + "_end"]
+        idx = np.where((rounds > 16) & (end == 0))[0][::3]
+        assert len(idx) >= 30
+        res = {}
+        for rule in ("ldl", "lapack"):
+            same = scan_is_reference = 0
+            for i in idx:
+                cache = {}
+
+                def neg(r):
+                    if r not in cache:
+                        Q = Q0[i].copy()
+                        with np.errstate(over="ignore", invalid="ignore"):
+                            for k in range(r):
+                                Q = Q + np.ldexp(Pm[i], k)
+                        cache[r] = oracle.has_negative_eig(Q, rule=rule) == 1
+                    return cache[r]
+                scan = 0
+                while neg(scan) and scan < 1300:
+                    scan += 1
+                lo, hi = -1, -1
+                while hi < 0 or hi - lo > 1:
+                    rt = (lo + 1 if lo < 16 else min(2 * lo, 1300)) if hi < 0 else (lo + hi) // 2
+                    if neg(rt) and rt < 1300:
+                        lo = rt
+                    else:
+                        hi = rt
+                same += hi == scan
+                scan_is_reference += scan == rounds[i]
+            res[rule] = (same / len(idx), scan_is_reference / len(idx))
+        print(tag, "search == scan, scan == reference:", res)
+        assert res["ldl"][0] >= min_same_ldl           # the search finds the scan's round for most stages under its own rule
+        assert res["lapack"][1] == 1.0                 # LAPACK's rule, scanned one by one, is the reference
+        assert res["ldl"][1] <= 0.1                    # the LDL' rule is not, search or scan
