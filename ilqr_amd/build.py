@@ -35,13 +35,15 @@ class DeviceCallLeft(RuntimeError):
     pass
 
 
-def check_everything_inlined(remarks: str, unit: str):
+def check_everything_inlined(remarks: str, unit: str, may_be_empty: bool = False):
     """Every device function a kernel uses must have been inlined into it.  A kernel's scratch size is then what
     its own body spills; with a callee left out of line the size travels from callee to caller through assembler
     symbols, and builds were seen in which that came out as 0 for a callee with a 676-byte frame (its stack accesses
     then leave the wave's scratch window: a memory aperture violation on the GPU).  The compiler's resource report
     names every function it emitted code for: anything that is not a kernel fails the build."""
     names = re.findall(r"remark: Function Name: (\S+)", remarks)
+    if not names and may_be_empty:
+        return
     if not names:
         raise DeviceCallLeft(f"{unit}: no resource report from the compiler (is -Rpass-analysis still passed?)")
     left = sorted({n for n in names if "kernel" not in n})
@@ -51,8 +53,9 @@ def check_everything_inlined(remarks: str, unit: str):
                              + (" ; a kernel has a dynamic stack" if dyn else ""))
 
 
-def build_library(out_so, defines=(), include_dirs=(), hipcc=None):
-    """Compile both translation units with the given -D / -I options and link them into out_so."""
+def build_library(out_so, defines=(), include_dirs=(), hipcc=None, no_kernels_in=()):
+    """Compile both translation units with the given -D / -I options and link them into out_so.
+    no_kernels_in: units that hold no kernel in this configuration (no resource report is expected from them)."""
     hipcc = hipcc or os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out_dir = os.path.dirname(out_so)
     os.makedirs(out_dir, exist_ok=True)
@@ -73,7 +76,7 @@ def build_library(out_so, defines=(), include_dirs=(), hipcc=None):
                 print(rest)
             if p.returncode != 0:
                 raise subprocess.CalledProcessError(p.returncode, p.args)
-            check_everything_inlined(err, src)
+            check_everything_inlined(err, src, may_be_empty=src in no_kernels_in)
         tmp = os.path.join(out_dir, f".{tag}.so")
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp, *objs])
         os.replace(tmp, out_so)

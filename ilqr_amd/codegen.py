@@ -25,6 +25,7 @@ from sympy.printing.c import C99CodePrinter
 _HERE = os.path.dirname(os.path.abspath(__file__))
 VERBOSE = False
 MAX_USER_W = 8        # nx + nu the lane-per-trajectory backward stage is built for (everything in registers)
+WIDE_NX, WIDE_NU = 12, 4   # a plant beyond that is solved as a 12-state, 4-control plant by the 16-lane kernels
 
 
 class _Printer(C99CodePrinter):
@@ -194,9 +195,10 @@ HEADER = """/* GENERATED by tools/gen_models.py -- do not edit.
 def user_expressions(nx, nu, n_par, dynamics, cost_stage, cost_final):
     """Run the user's functions once on SymPy symbols: dynamics(x, u, p), cost_stage(x, u, p), cost_final(x, p).
     Returns (xs, us, ps, f [nx], l, lf)."""
-    if nx + nu > MAX_USER_W:
+    if nx + nu > MAX_USER_W and (nx > WIDE_NX or nu > WIDE_NU):
         raise NotImplementedError(
-            f"nx + nu = {nx + nu} > {MAX_USER_W}: the backward stage for user plants keeps every matrix in registers")
+            f"nx = {nx}, nu = {nu}: plants with nx + nu > {MAX_USER_W} are solved by the kernels built for "
+            f"{WIDE_NX} states and {WIDE_NU} controls, so nx <= {WIDE_NX} and nu <= {WIDE_NU}")
     import numpy as np
     xs = sp.symbols(f"x0:{nx}", real=True)
     us = sp.symbols(f"u0:{nu}", real=True)
@@ -212,7 +214,26 @@ def user_expressions(nx, nu, n_par, dynamics, cost_stage, cost_final):
     return xs, us, ps, f, l, lf
 
 
-CODEGEN_VERSION = "1"   # part of the library key: bump when the printed C or the solver sources change meaning
+def is_wide(nx, nu):
+    return nx + nu > MAX_USER_W
+
+
+def pad_wide(nx, nu, exprs):
+    """The same plant stated with WIDE_NX states and WIDE_NU controls, which is what the 16-lane backward kernel is
+    written for.  The added states are constant zero (f = 0, no cost) and the added controls cost u^2/2 and move
+    nothing: every term of the solver that involves them vanishes identically (their rows and columns of f_x, f_u, l_xx
+    are zero, their Q_u is zero, so d = 0 and K = 0 for them, and the blocks 0 and I they add to the Q-function
+    Hessian do not change which of its eigenvalues are negative), so cost, decisions and the real part of the
+    trajectory are those of the plant as written."""
+    xs, us, ps, f, l, lf = exprs
+    xp = tuple(xs) + sp.symbols(f"x{nx}:{WIDE_NX}", real=True)
+    up = tuple(us) + sp.symbols(f"u{nu}:{WIDE_NU}", real=True)
+    fp = sp.Matrix(list(f) + [sp.Integer(0)] * (WIDE_NX - nx))
+    lp = l + sp.Rational(1, 2) * sum(v * v for v in up[nu:])
+    return xp, up, ps, fp, lp, lf
+
+
+CODEGEN_VERSION = "2"   # part of the library key: bump when the printed C or the solver sources change meaning
 
 
 def user_key(nx, nu, n_par, exprs):
@@ -225,6 +246,11 @@ def user_key(nx, nu, n_par, exprs):
 def generate_user_header(nx, nu, n_par, exprs, name="user"):
     """C text of user_gen.h: USER_NX / USER_NU / USER_NP and user_gen_{dynamics,cost_stage,cost_final,stage,final}
     with the signatures of the car's generated functions."""
+    wide = is_wide(nx, nu)
+    real_nx, real_nu = nx, nu
+    if wide:
+        exprs = pad_wide(nx, nu, exprs)
+        nx, nu = WIDE_NX, WIDE_NU
     xs, us, ps, f, l, lf = exprs
     lx = sp.Matrix([l]).jacobian(xs)
     lu = sp.Matrix([l]).jacobian(us)
@@ -232,7 +258,11 @@ def generate_user_header(nx, nu, n_par, exprs, name="user"):
     ins = [("p", ps), ("x", xs), ("u", us)]
     out = HEADER.format(what=f"User-defined plant '{name}' (the Model interface of control/models/model.py:9-43).")
     out = out.replace("GENERATED by tools/gen_models.py", "GENERATED by ilqr_amd/codegen.py")
-    out += f"#define USER_NX {nx}\n#define USER_NU {nu}\n#define USER_NP {max(1, n_par)}\n\n"
+    out += f"#define USER_NX {nx}\n#define USER_NU {nu}\n#define USER_NP {max(1, n_par)}\n"
+    out += f"#define USER_REAL_NX {real_nx}\n#define USER_REAL_NU {real_nu}\n"
+    if wide:
+        out += "#define USER_WIDE 1   /* stated with 12 states and 4 controls for the 16-lane backward kernel */\n"
+    out += "\n"
     parts = [
         ("user_gen_dynamics", ins, [("xn", f)], "x_next = discrete_dynamics(x, u)"),
         ("user_gen_cost_stage", ins, [("c", [l])], "stage cost"),
@@ -242,6 +272,18 @@ def generate_user_header(nx, nu, n_par, exprs, name="user"):
          "stage derivatives: l_x l_u l_xx l_ux l_uu f_x f_u (row-major)"),
         ("user_gen_final", ins[:2], [("V_x", lfx), ("V_xx", lfx.jacobian(xs))], "final-cost derivatives"),
     ]
+    if wide:
+        # what lane j of a team asks for: column j of [f_x f_u] as a directional derivative, and the cost terms of the
+        # joint variable z = (x, u) in one piece
+        vx = sp.symbols(f"vx0:{nx}", real=True)
+        vu = sp.symbols(f"vu0:{nu}", real=True)
+        jv = f.jacobian(xs) * sp.Matrix(vx) + f.jacobian(us) * sp.Matrix(vu)
+        parts.append(("user_gen_dynamics_jvp", ins + [("vx", vx), ("vu", vu)], [("jv", jv)],
+                      "(d x_next/dx) vx + (d x_next/du) vu"))
+        zs = list(xs) + list(us)
+        lz = sp.Matrix([l]).jacobian(zs)
+        parts.append(("user_gen_cost_terms", ins, [("l_z", lz), ("l_zz", lz.jacobian(zs))],
+                      "l_z [16] = [l_x l_u], l_zz [16x16] = [[l_xx, l_ux'], [l_ux, l_uu]]"))
     for fname, fins, fouts, doc in parts:
         text, _ = emit_function(fname, fins, fouts, doc)
         out += text
@@ -267,7 +309,9 @@ def build_user_library(nx, nu, n_par, exprs, name, out_root=None, hipcc=None, fo
     with open(os.path.join(d, "user_gen.h"), "w") as fh:
         fh.write(generate_user_header(nx, nu, n_par, exprs, name))
     from .build import build_library
-    build_library(so, defines=("ILQR_USER_MODEL", "ILQR_ONLY_USER"), include_dirs=(d,), hipcc=hipcc)
+    # (a plant stated with 12 + 4 takes the 16-lane kernels of the main unit: the lane-per-trajectory unit is empty)
+    build_library(so, defines=("ILQR_USER_MODEL", "ILQR_ONLY_USER"), include_dirs=(d,), hipcc=hipcc,
+                  no_kernels_in=("lane_plants.hip",) if is_wide(nx, nu) else ())
     with open(stamp_file, "w") as fh:
         fh.write(stamp + "\n")
     return so

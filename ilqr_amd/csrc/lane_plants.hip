@@ -6,7 +6,7 @@ namespace ilqr {
 #ifndef ILQR_ONLY_USER
 template int run_part<CarModel, false>(Pipe, hipStream_t, ilqr_timing*);
 #endif
-#ifdef ILQR_USER_MODEL
+#if defined(ILQR_USER_MODEL) && !defined(USER_WIDE)
 template int run_part<UserModel, false>(Pipe, hipStream_t, ilqr_timing*);
 #endif
 }  // namespace ilqr

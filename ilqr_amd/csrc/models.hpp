@@ -87,14 +87,25 @@ struct CarModel {
 // symbolically (car.py:30-52).  Here those three functions were traced once and
 // printed as user_gen_* with the car's signatures; par holds USER_NP numbers
 // the user may change between solves without rebuilding.
+// A plant with nx + nu > 8 arrives here stated with 12 states and 4 controls (USER_WIDE; the added states are
+// constant zero, the added controls cost u^2/2 and move nothing) and takes the 16-lanes-per-trajectory backward
+// kernel of the quadrotors.
 struct UserModel {
     static constexpr int NX = USER_NX, NU = USER_NU, NDX = USER_NX, NPAR = USER_NP;
-    static constexpr bool UNROLL = true;
-    static constexpr bool TEAM_BACKWARD = false;
     static constexpr bool HAS_CONTINUOUS = false;
     static constexpr int BACKWARD_WAVES = 1;
+#ifdef USER_WIDE
+    static constexpr bool UNROLL = false;
+    static constexpr bool TEAM_BACKWARD = true;
+    static constexpr long TAIL_COUNT = 8192;
+    static_assert(NX == 12 && NU == 4, "wide user plants are stated with 12 states and 4 controls");
+    __device__ static bool euler(const double*) { return false; }      // (the plant states its own step)
+#else
+    static constexpr bool UNROLL = true;
+    static constexpr bool TEAM_BACKWARD = false;
     static constexpr long TAIL_COUNT = 16384;
     static_assert(NX + NU <= 8, "the lane-per-trajectory backward stage keeps every matrix in registers");
+#endif
     __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
     {
         user_gen_dynamics(par, x, u, xn);

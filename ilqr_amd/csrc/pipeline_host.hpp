@@ -220,7 +220,7 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
 #ifndef ILQR_ONLY_USER
 extern template int run_part<CarModel, false>(Pipe, hipStream_t, ilqr_timing*);
 #endif
-#ifdef ILQR_USER_MODEL
+#if defined(ILQR_USER_MODEL) && !defined(USER_WIDE)      // (a wide user plant takes the 16-lane kernels of the main unit)
 extern template int run_part<UserModel, false>(Pipe, hipStream_t, ilqr_timing*);
 #endif
 #endif

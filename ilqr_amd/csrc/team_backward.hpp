@@ -126,7 +126,7 @@ struct TeamOps<QuadraticRK4Model<12, 4, U, XD, XJ, XV>> {
             shared[e] = v;
         }
     }
-    __device__ static void column(double dt, bool eul, const double* xu, int j, double*, double* col)
+    __device__ static void column(const double*, double dt, bool eul, const double* xu, int j, double*, double* col)
     {
         double vx[n], vu[m];
 #pragma unroll
@@ -203,7 +203,7 @@ struct TeamOps<QuadQuatModel> {
         for (int t = 4; t < 13; ++t) pick = (t - 1 == c) ? v[t] : pick;
         return (c < 3) ? s : pick;
     }
-    __device__ static void column(double dt, bool eul, const double* xu, int j, double*, double* col)
+    __device__ static void column(const double*, double dt, bool eul, const double* xu, int j, double*, double* col)
     {
         double G[12], vx[13], vu[m], dxn[13];
         quad_quat_gen_G(xu, G);
@@ -270,6 +270,48 @@ struct TeamOps<QuadQuatModel> {
     }
 };
 
+#if defined(ILQR_USER_MODEL) && defined(USER_WIDE)
+// a plant the user wrote, stated with 12 states and 4 controls (models.hpp): the generated functions give the
+// directional derivative of the step and the cost terms of z = (x, u) in one piece
+template <>
+struct TeamOps<UserModel> {
+    using M = UserModel;
+    static constexpr int n = 12, m = 4, w = 16;
+    static constexpr int SHARED = 0, EXTRA = w + w * w;
+    __device__ static void setup(const double*, int, double*) {}
+    __device__ static void setup_team(const double*, int, double*) {}
+    __device__ static void column(const double* par, double, bool, const double* xu, int j, double*, double* col)
+    {
+        double vx[n], vu[m];
+#pragma unroll
+        for (int c = 0; c < n; ++c) vx[c] = (c == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int c = 0; c < m; ++c) vu[c] = (c + n == j) ? 1.0 : 0.0;
+        user_gen_dynamics_jvp(par, xu, xu + n, vx, vu, col);
+    }
+    __device__ static void cost_row(const double* par, const double* xu, int j, const double*, double* ex, double& lz,
+                                    double* lzz)
+    {
+        // every lane of the team writes the same values: l_z (16), l_zz (16 x 16)
+        user_gen_cost_terms(par, xu, xu + n, ex, ex + w);
+        wave_sync();
+        lz = ex[j];
+#pragma unroll
+        for (int c = 0; c < w; ++c) lzz[c] = ex[w + j * w + c];
+    }
+    __device__ static void final_row(const double* par, const double* x, int j, const double*, double* ex, double& vx,
+                                     double* vrow)
+    {
+        user_gen_final(par, x, ex, ex + w);       // V_x (12), V_xx (12 x 12)
+        wave_sync();
+        const int jj = (j < n) ? j : 0;
+        vx = ex[jj];
+#pragma unroll
+        for (int c = 0; c < n; ++c) vrow[c] = ex[w + jj * n + c];
+    }
+};
+#endif
+
 // PT: one parameter block per trajectory (at a.par + id * a.par_block) instead of one for all.
 template <class M, bool PT = false>
 __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
@@ -324,7 +366,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
         const bool alive = live && ok;
         // ---- column j of F = [f_x f_u]: derivative of the RK4 step along unit vector j
         double col[n];
-        OPS::column(step_dt, step_euler, xu, j, EX, col);
+        OPS::column(par, step_dt, step_euler, xu, j, EX, col);
         wave_sync();        // everybody is done with the previous stage's LDS data
 #pragma unroll
         for (int r = 0; r < n; ++r) L[tl::F + r * w + j] = col[r];

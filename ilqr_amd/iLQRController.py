@@ -92,11 +92,13 @@ class iLQR:
         if single:
             if tuple(u_trj.shape) != (S, self.nu):
                 raise ValueError(f"u_trj must have shape ({S}, {self.nu}), got {tuple(u_trj.shape)}")
-            res = solver.solve(x0a[None], u_trj[None])
+            res = solver.solve(self.model._lib_x(x0a[None]), self.model._lib_u(u_trj[None]))
         else:
             if tuple(u_trj.shape) != (x0a.shape[0], S, self.nu):
                 raise ValueError(f"u_trj must have shape (B, {S}, {self.nu}), got {tuple(u_trj.shape)}")
-            res = solver.solve(x0a, u_trj)
+            res = solver.solve(self.model._lib_x(x0a), self.model._lib_u(u_trj))
+        res.x = self.model._own("x", res.x)       # (the library may state the plant wider than it was written)
+        res.u = self.model._own("u", res.u)
         self.info = res
         status = res.status.cpu().numpy()
         # reference counters: reset at every iteration that reaches the line search (:57-58), so after the call

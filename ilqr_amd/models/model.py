@@ -47,11 +47,22 @@ class Model:
             cache[key] = BatchSolver(self._model_id, par, int(N), 1, 1, 0.0, library=getattr(self, "_library", None))
         return cache[key]
 
+    # The solver library may state the plant with more states / controls than the plant as written (user plants with
+    # nx + nu > 8, ilqr_amd/models/user.py): arrays go in through _lib_x / _lib_u and come back through _own.
+    def _lib_x(self, x):
+        return x
+
+    def _lib_u(self, u):
+        return u
+
+    def _own(self, key, a):
+        return a
+
     def _eval(self, x, u, what):
         x = np.asarray(x, dtype=np.float64).reshape(1, self.nx)
         u = np.zeros((1, self.nu)) if u is None else np.asarray(u, dtype=np.float64).reshape(1, self.nu)
-        out = self._evaluator().model_eval(x, u, what)
-        return [out[k][0].cpu().numpy() for k in what]
+        out = self._evaluator().model_eval(self._lib_x(x), self._lib_u(u), what)
+        return [self._own(k, out[k][0].cpu().numpy()) for k in what]
 
     # ------------------------------------------------------------ interface
     def get_dims(self):
@@ -63,8 +74,9 @@ class Model:
     def rollout(self, x0, u_trj):
         """model.py:15-20: x_trj [len(u_trj)+1, nx]."""
         u_trj = np.asarray(u_trj, dtype=np.float64)
-        x, _ = self._evaluator(u_trj.shape[0] + 1).rollout_cost(np.asarray(x0, dtype=np.float64)[None], u_trj[None])
-        return x[0].cpu().numpy()
+        x, _ = self._evaluator(u_trj.shape[0] + 1).rollout_cost(self._lib_x(np.asarray(x0, dtype=np.float64)[None]),
+                                                                 self._lib_u(u_trj[None]))
+        return self._own("x", x[0].cpu().numpy())
 
     def CalcDifferentialState(self, state, ref_state):
         return np.asarray(state) - np.asarray(ref_state)       # model.py:22-23
@@ -82,7 +94,7 @@ class Model:
         u_trj = np.asarray(u_trj, dtype=np.float64)
         ev = self._evaluator()
         S = u_trj.shape[0]
-        out = ev.model_eval(x_trj[:S], u_trj, ("cs",))["cs"].cpu().numpy()
+        out = ev.model_eval(self._lib_x(x_trj[:S]), self._lib_u(u_trj), ("cs",))["cs"].cpu().numpy()
         total = 0.0
         for c in out:
             total += float(c)

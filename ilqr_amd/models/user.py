@@ -27,8 +27,13 @@ solver for that plant into its own shared library under ilqr_amd/lib/user/.
 After `build()` the Model interface (discrete_dynamics, stage, final, rollout,
 cost_trj, ...) evaluates on the GPU like the shipped plants; the Python methods
 the user wrote stay reachable as `python_dynamics`, `python_cost_stage`,
-`python_cost_final`.  State plus control dimension is limited to 8 (the
-lane-per-trajectory backward stage keeps every matrix in registers).
+`python_cost_final`.  Plants with nx + nu <= 8 are solved one trajectory per
+lane; larger ones (nx <= 12, nu <= 4) are handed to the library stated with 12
+states and 4 controls (added states constant zero, added controls costing
+u^2/2 and moving nothing: the solve is that of the plant as written) and take the
+16-lanes-per-trajectory kernels of the quadrotors; arrays are widened on the
+way in and cut back on the way out, so the Python interface keeps the plant's
+own dimensions.  One parameter set per batch for those.
 """
 from __future__ import annotations
 
@@ -118,6 +123,41 @@ class UserModel(Model):
         for meth in ("discrete_dynamics", "_cost_stage", "_cost_final"):
             setattr(self, meth, types.MethodType(getattr(Model, meth), self))
 
+    # ------------------------------------------------------------ plants the library states wider than written
+    def _wide(self):
+        from .. import codegen
+        return codegen.is_wide(self.nx, self.nu)
+
+    def _widen(self, a, have, want):
+        if not self._wide():
+            return a
+        import torch
+        if torch.is_tensor(a):
+            pad = torch.zeros(a.shape[:-1] + (want - have,), dtype=a.dtype, device=a.device)
+            return torch.cat([a, pad], dim=-1)
+        a = np.asarray(a, dtype=np.float64)
+        return np.concatenate([a, np.zeros(a.shape[:-1] + (want - have,))], axis=-1)
+
+    def _lib_x(self, x):
+        from .. import codegen
+        return self._widen(x, self.nx, codegen.WIDE_NX)
+
+    def _lib_u(self, u):
+        from .. import codegen
+        return self._widen(u, self.nu, codegen.WIDE_NU)
+
+    def _own(self, key, a):
+        if not self._wide():
+            return a
+        n, m = self.nx, self.nu
+        cut = dict(x=(n,), xn=(n,), u=(m,), l_x=(n,), l_u=(m,), l_xx=(n, n), l_ux=(m, n), l_uu=(m, m), f_x=(n, n),
+                   f_u=(n, m), V_x=(n,), V_xx=(n, n)).get(key)
+        if cut is None:
+            return a
+        if len(cut) == 1:
+            return a[..., :cut[0]]
+        return a[..., :cut[0], :cut[1]]
+
     def _param_block(self):
         if self._library is None:
             raise RuntimeError(f"{type(self).__name__}: call build() (or use_library()) before solving")
@@ -128,6 +168,8 @@ class UserModel(Model):
         trajectory of the batches solved from now on (batched goals; no rebuild either way)."""
         p = np.asarray(params, dtype=np.float64)
         n = self.p.shape[-1]
+        if p.ndim == 2 and self._wide():
+            raise ValueError("a plant with nx + nu > 8 takes one parameter set per batch")
         if p.ndim == 2 and p.shape[1] == n and n > 0:
             self.p = np.ascontiguousarray(p)
             return

@@ -540,6 +540,15 @@ def gen_user_rover(pool):
     run_cases("user_rover", dict(model="user", cls="Rover"), ROVER_SP, x0, u0, pool)
 
 
+def gen_user_tug(pool):
+    """A plant defined by the user with nx + nu = 9 (tests/user_models.py Tug): the reference solves it as written,
+    the library as a 12-state, 4-control plant."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from user_models import TUG_SP, tug_inputs
+    x0, u0 = tug_inputs(32, 77)
+    run_cases("user_tug", dict(model="user", cls="Tug"), TUG_SP, x0, u0, pool)
+
+
 def gen_quat_utils(pool):
     """Outputs of the reference's NumPy quaternion helpers (maths/quaternions.py) on random quaternions."""
     from maths import quaternions as rq
@@ -556,7 +565,7 @@ def gen_quat_utils(pool):
     print("[golden] quat_utils: 32 quaternions", flush=True)
 
 
-GENS = dict(quat_utils=gen_quat_utils, user_rover=gen_user_rover, car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
+GENS = dict(quat_utils=gen_quat_utils, user_rover=gen_user_rover, user_tug=gen_user_tug, car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
             acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat, baseline=gen_baseline_horizons, variants=gen_variants, units=gen_units)
 
 

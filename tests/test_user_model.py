@@ -15,7 +15,7 @@ import pytest
 
 from conftest import ROOT, load_golden
 from helpers import compare_to_golden, rel_traj
-from user_models import ROVER_SP, Rover, rover_inputs
+from user_models import ROVER_SP, TUG_SP, Rover, Tug, rover_inputs, tug_inputs
 
 
 @pytest.fixture(scope="module")
@@ -94,8 +94,12 @@ def test_user_model_contract():
             return x[0] ** 2
 
     with pytest.raises(NotImplementedError, match="nx \\+ nu"):
-        Wide(7, 2).trace()
+        Wide(13, 2).trace()
+    with pytest.raises(NotImplementedError, match="nx \\+ nu"):
+        Wide(6, 5).trace()
     assert len(Wide(3, 1).trace()[3]) == 3
+    assert len(Wide(7, 2).trace()[3]) == 7          # traced as written; stated with 12 + 4 only for the library
+    assert "#define USER_NX 12" in Wide(7, 2).header_text() and "#define USER_REAL_NX 7" in Wide(7, 2).header_text()
 
     class WrongLen(Wide):
         def discrete_dynamics(self, x, u):
@@ -107,6 +111,34 @@ def test_user_model_contract():
         iLQR(Rover(), **dict(N=10, max_iter=1))._get_solver()
     with pytest.raises(ValueError, match="traced with 4"):
         Rover().set_params([1.0])
+
+
+# ------------------------------------------------------------------- nx + nu > 8: stated as 12 states, 4 controls
+@pytest.fixture(scope="module")
+def tug_checker(oracle, tmp_path_factory):
+    d = tmp_path_factory.mktemp("tug_hdr")
+    (d / "user_gen.h").write_text(Tug().header_text())
+    return oracle.build_user(str(d), out_dir=str(d))
+
+
+def _widen(a, want):
+    return np.concatenate([a, np.zeros(a.shape[:-1] + (want - a.shape[-1],))], axis=-1)
+
+
+def test_widened_plant_solves_like_the_plant_as_written(oracle, tug_checker):
+    """The reference's iLQR ran the 6-state, 3-control plant as written (tests/golden/user_tug.npz); the checker
+    compiled with the generated header solves the 12-state, 4-control statement of it: same decisions, same cost, and
+    the real part of the trajectory within the parity bar; the added states and controls stay zero."""
+    g = load_golden("user_tug")
+    assert oracle.dims("user", tug_checker) == (12, 4, 12, 4)
+    r = oracle.solve_batch("user", g["par"], int(g["N"]), int(g["max_iter"]), int(g["max_ls"]), float(g["d_tol"]),
+                           _widen(g["x0"], 12), _widen(g["u_init"], 4), library=tug_checker)
+    i = r["info"]
+    assert not r["x"][:, :, 6:].any() and not r["u"][:, :, 3:].any()
+    n = compare_to_golden(g, r["x"][:, :, :6], r["u"][:, :, :3], i["J_last"], i["iters"], i["status"], i["ls_evals"],
+                          i["accepted"], i["regu_rounds"], J0=i["J0"], label="user_tug")
+    assert n >= 28
+    assert (g["regu_rounds"] > 0).all() and (g["ls_evals"] > 1).any()
 
 
 # ----------------------------------------------------------------------------------------------- GPU
@@ -187,3 +219,61 @@ def test_user_plant_model_interface_on_gpu(oracle, rover_gpu, rover_checker_gpu)
         _lib.model_info(_lib.MODEL_CAR, _lib.lib(rover_gpu._library))
     with pytest.raises(RuntimeError, match="unknown model_id"):
         _lib.model_info(_lib.MODEL_USER)
+
+
+@pytest.fixture(scope="module")
+def tug_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    plant = Tug()
+    return plant.use_library(os.path.join(plant.library_dir(), "libilqr_user.so"))
+
+
+@pytest.mark.gpu
+def test_wide_user_plant_on_gpu_matches_reference_golden(tug_gpu):
+    """nx + nu = 9: the 16-lanes-per-trajectory kernels on the plant stated with 12 states and 4 controls, against the
+    reference's solve of the plant as written."""
+    g = load_golden("user_tug")
+    tug_gpu.set_params(g["par"])
+    sp = dict(N=int(g["N"]), max_iter=int(g["max_iter"]), max_ls=int(g["max_ls"]), d_tol=float(g["d_tol"]))
+    info, x, u = _solve(tug_gpu, sp, g["x0"], g["u_init"])
+    assert x.shape == (32, 50, 6) and u.shape == (32, 49, 3)
+    t = info.traces
+    n = compare_to_golden(g, x, u, info.J.cpu().numpy(), info.iters.cpu().numpy(), info.status.cpu().numpy(),
+                          t["ls_evals"].cpu().numpy(), t["accepted"].cpu().numpy(), info.regu_rounds.cpu().numpy(),
+                          J0=info.J0.cpu().numpy(), label="user_tug")
+    assert n >= 28
+
+
+@pytest.mark.gpu
+def test_wide_user_plant_batch_and_model_interface_on_gpu(oracle, tug_gpu):
+    par = np.array([1.5, -1.0, 0.6, -0.4])
+    tug_gpu.set_params(par)
+    chk = oracle.build_user(tug_gpu.library_dir())
+    x0, u0 = tug_inputs(256, 5)
+    info, x, u = _solve(tug_gpu, TUG_SP, x0, u0)
+    r = oracle.solve_batch("user", par, TUG_SP["N"], TUG_SP["max_iter"], TUG_SP["max_ls"], TUG_SP["d_tol"],
+                           _widen(x0, 12), _widen(u0, 4), library=chk)
+    i = r["info"]
+    same = ((info.iters.cpu().numpy() == i["iters"]) & (info.status.cpu().numpy() == i["status"])
+            & (info.regu_rounds.cpu().numpy() == i["regu_rounds"]) & (info.ls_total.cpu().numpy() == i["ls_total"]))
+    assert same.mean() >= 0.9, same.mean()
+    rx = rel_traj(x[same], r["x"][same][:, :, :6]); ru = rel_traj(u[same], r["u"][same][:, :, :3])
+    assert ((rx <= 1e-8) & (ru <= 1e-8)).mean() >= 0.9
+    # the Model interface keeps the plant's own dimensions
+    assert tug_gpu.get_dims() == (6, 3, 6)
+    rng = np.random.default_rng(1)
+    xs, us = rng.uniform(-1, 1, 6), rng.standard_normal(3)
+    assert np.allclose(tug_gpu.discrete_dynamics(xs, us), tug_gpu.python_dynamics(xs, us), rtol=1e-13, atol=1e-15)
+    assert np.isclose(tug_gpu._cost_stage(xs, us), tug_gpu.python_cost_stage(xs, us), rtol=1e-12)
+    lx, lu, lxx, lux, luu, fx, fu = tug_gpu.stage(xs, us)
+    assert lx.shape == (6,) and lxx.shape == (6, 6) and lux.shape == (3, 6) and fx.shape == (6, 6) and fu.shape == (6, 3)
+    h = 1e-6
+    fd = np.column_stack([(tug_gpu.python_dynamics(xs + h * np.eye(6)[k], us) - tug_gpu.python_dynamics(xs - h * np.eye(6)[k], us))
+                          / (2 * h) for k in range(6)])
+    assert np.allclose(fx, fd, rtol=1e-6, atol=1e-8)
+    xt = tug_gpu.rollout(xs, np.tile(us, (5, 1)))
+    assert xt.shape == (6, 6) and np.allclose(xt[1], tug_gpu.python_dynamics(xs, us), rtol=1e-13, atol=1e-15)
+    with pytest.raises(ValueError, match="one parameter set"):
+        tug_gpu.set_params(np.zeros((4, 4)))

@@ -45,3 +45,44 @@ def rover_inputs(B, seed):
                           rng.uniform(0, 1.5, B)])
     u0 = 0.3 * rng.standard_normal((B, ROVER_SP["N"] - 1, 2))
     return x0, u0
+
+
+class Tug(UserModel):
+    """Planar rigid body with two body-frame thrusters and a reaction wheel, pushing to a goal pose past a soft keep-out
+    disc: nx + nu = 9, beyond the one-trajectory-per-lane kernels.
+
+    x = [px, py, heading, vx, vy, turn rate], u = [surge force, sway force, torque], p = [goal_x, goal_y, disc_x, disc_y].
+    """
+    DT = 0.1
+
+    def __init__(self, goal=(2.0, 1.0), disc=(1.0, 0.3)):
+        super().__init__(nx=6, nu=3, params=[*goal, *disc], name="tug")
+
+    def discrete_dynamics(self, x, u):
+        h = self.DT
+        c, s = m.cos(x[2]), m.sin(x[2])
+        return m.array([x[0] + h * x[3], x[1] + h * x[4], x[2] + h * x[5],
+                        x[3] + h * (c * u[0] - s * u[1] - 0.2 * x[3]),
+                        x[4] + h * (s * u[0] + c * u[1] - 0.2 * x[4]),
+                        x[5] + h * (2.0 * u[2] - 0.3 * x[5])])
+
+    def _cost_stage(self, x, u):
+        goal = (x[0] - self.p[0]) ** 2 + (x[1] - self.p[1]) ** 2
+        d2 = (x[0] - self.p[2]) ** 2 + (x[1] - self.p[3]) ** 2
+        return (0.05 * goal + 3.0 * m.exp(-d2 / 0.2) + 0.02 * (x[3] ** 2 + x[4] ** 2 + x[5] ** 2) + 0.02 * x[2] ** 2
+                + 0.1 * u[0] ** 2 + 0.1 * u[1] ** 2 + 0.2 * u[2] ** 2)
+
+    def _cost_final(self, x):
+        goal = (x[0] - self.p[0]) ** 2 + (x[1] - self.p[1]) ** 2
+        return 40.0 * goal + 10.0 * x[2] ** 2 + 5.0 * (x[3] ** 2 + x[4] ** 2 + x[5] ** 2)
+
+
+TUG_SP = dict(N=50, max_iter=40, max_ls=20, d_tol=1e-3)
+
+
+def tug_inputs(B, seed):
+    rng = np.random.default_rng(seed)
+    x0 = np.column_stack([rng.uniform(-1, 0.5, B), rng.uniform(-1, 1, B), rng.uniform(-1.5, 1.5, B),
+                          0.3 * rng.standard_normal((B, 3))])
+    u0 = 0.2 * rng.standard_normal((B, TUG_SP["N"] - 1, 3))
+    return x0, u0
