@@ -290,12 +290,16 @@ def main():
                 with np.errstate(invalid="ignore"):
                     err = np.abs(xg - ref["x"]).reshape(c, -1).max(1) / scale
                 sel = err[repro & same] if (repro & same).any() else np.array([np.nan])
+                # the bar of the tests (tests/helpers.py): 1e-8, or 100 times what the checker's own answer moves under
+                # the 1e-14 perturbation where that is more
+                bar = np.maximum(1e-8, 100.0 * drift)[repro & same] if (repro & same).any() else np.array([np.nan])
                 calm = i1["max_abs_q"] < 1e5
                 res["parity_check"] = {"checked": int(c), "reproducible": int(repro.sum()),
                                        "reproducible_same_decisions": int((repro & same).sum()),
                                        "max_rel_x_err_reproducible": float(np.nanmax(sel)),
                                        "median_rel_x_err_reproducible": float(np.nanmedian(sel)),
                                        "frac_rel_x_err_le_1e-8_reproducible": float((sel <= 1e-8).mean()),
+                                       "frac_within_parity_bar_reproducible": float((sel <= bar).mean()),
                                        "all_same_iters_and_exit": int(same.sum()),
                                        "max_abs_q_below_1e5": int(calm.sum()),
                                        "max_abs_q_below_1e5_same_decisions": int((calm & same).sum()),
