@@ -171,7 +171,9 @@ struct TeamOps<QuadQuatModel> {
     static constexpr int n = 12, m = 4, w = 16;
     // shared: the symmetrised weights [(Q + Q')/2, (Qf + Qf')/2, (R + R')/2], formed once per kernel, then xref (13)
     // and uref (4): inside the stage loop nothing is read through the parameter pointer
-    static constexpr int XREF = M::SYM_WEIGHTS, UREF = XREF + 13, SHARED = UREF + 4 + 1, EXTRA = 13 + 4 + 169 + 1 + M::COST_WORK;
+    static constexpr int XREF = M::SYM_WEIGHTS, UREF = XREF + 13, SHARED = UREF + 4 + 1 /* even */;
+    // per team: l_x (13), l_u (4), l_xx (13 x 13), then the cost's work arrays at an even offset
+    static constexpr int WORK = 188, EXTRA = WORK + M::COST_WORK;
     __device__ static double shared_entry(const double* par, int e)
     {
         if (e < XREF) return M::sym_weight(par, e);
@@ -249,7 +251,7 @@ struct TeamOps<QuadQuatModel> {
         double G[12];
         quad_quat_gen_G(xu, G);
         // every lane of the team writes the same values: l_x (13), l_u (4), l_xx (13 x 13)
-        M::cost_derivs_sym(shared, shared + 288, shared + XREF, shared + UREF, false, xu, xu + 13, ex, ex + 13, ex + 17, ex + 187);
+        M::cost_derivs_sym(shared, shared + 288, shared + XREF, shared + UREF, false, xu, xu + 13, ex, ex + 13, ex + 17, ex + WORK);
         wave_sync();
         double gj, row[n];
         project_row(G, ex, (j < n) ? j : 0, gj, row);
@@ -264,7 +266,7 @@ struct TeamOps<QuadQuatModel> {
     {
         double G[12];
         quad_quat_gen_G(x, G);
-        M::cost_derivs_sym(shared + 144, shared + 288, shared + XREF, shared + UREF, true, x, shared + UREF, ex, ex + 13, ex + 17, ex + 187);
+        M::cost_derivs_sym(shared + 144, shared + 288, shared + XREF, shared + UREF, true, x, shared + UREF, ex, ex + 13, ex + 17, ex + WORK);
         wave_sync();
         project_row(G, ex, (j < n) ? j : 0, vx, vrow);
     }
