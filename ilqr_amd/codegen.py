@@ -192,9 +192,10 @@ HEADER = """/* GENERATED by tools/gen_models.py -- do not edit.
 # ---------------------------------------------------------------------------
 # plants defined by the user
 # ---------------------------------------------------------------------------
-def user_expressions(nx, nu, n_par, dynamics, cost_stage, cost_final):
-    """Run the user's functions once on SymPy symbols: dynamics(x, u, p), cost_stage(x, u, p), cost_final(x, p).
-    Returns (xs, us, ps, f [nx], l, lf)."""
+def user_expressions(nx, nu, n_par, dynamics, cost_stage, cost_final, diff_state=None):
+    """Run the user's functions once on SymPy symbols: dynamics(x, u, p), cost_stage(x, u, p), cost_final(x, p) and,
+    if the plant overrides CalcDifferentialState (control/models/model.py:22-23), diff_state(state, ref_state, p).
+    Returns (xs, us, ps, f [nx], l, lf), with a seventh entry (ss, rs, dx [nx]) when diff_state is given."""
     if nx + nu > MAX_USER_W and (nx > WIDE_NX or nu > WIDE_NU):
         raise NotImplementedError(
             f"nx = {nx}, nu = {nu}: plants with nx + nu > {MAX_USER_W} are solved by the kernels built for "
@@ -211,7 +212,17 @@ def user_expressions(nx, nu, n_par, dynamics, cost_stage, cost_final):
         raise ValueError(f"discrete_dynamics returned {f.shape[0]} components, expected nx = {nx}")
     l = sp.sympify(cost_stage(x, u, p))
     lf = sp.sympify(cost_final(x, p))
-    return xs, us, ps, f, l, lf
+    if diff_state is None:
+        return xs, us, ps, f, l, lf
+    ss = sp.symbols(f"s0:{nx}", real=True)
+    rs = sp.symbols(f"r0:{nx}", real=True)
+    dx = sp.Matrix([sp.sympify(e) for e in np.asarray(diff_state(np.array(ss, dtype=object), np.array(rs, dtype=object), p),
+                                                       dtype=object).ravel()])
+    if dx.shape[0] != nx:
+        raise NotImplementedError(
+            f"CalcDifferentialState returned {dx.shape[0]} components for nx = {nx}: an error state of another dimension "
+            "needs the plant's own Q_terms as well (Quadrotor_Quat.py:267-275), which is not traced")
+    return xs, us, ps, f, l, lf, (ss, rs, dx)
 
 
 def is_wide(nx, nu):
@@ -225,12 +236,18 @@ def pad_wide(nx, nu, exprs):
     are zero, their Q_u is zero, so d = 0 and K = 0 for them, and the blocks 0 and I they add to the Q-function
     Hessian do not change which of its eigenvalues are negative), so cost, decisions and the real part of the
     trajectory are those of the plant as written."""
-    xs, us, ps, f, l, lf = exprs
+    xs, us, ps, f, l, lf = exprs[:6]
     xp = tuple(xs) + sp.symbols(f"x{nx}:{WIDE_NX}", real=True)
     up = tuple(us) + sp.symbols(f"u{nu}:{WIDE_NU}", real=True)
     fp = sp.Matrix(list(f) + [sp.Integer(0)] * (WIDE_NX - nx))
     lp = l + sp.Rational(1, 2) * sum(v * v for v in up[nu:])
-    return xp, up, ps, fp, lp, lf
+    if len(exprs) == 6:
+        return xp, up, ps, fp, lp, lf
+    ss, rs, dx = exprs[6]
+    sp_ = tuple(ss) + sp.symbols(f"s{nx}:{WIDE_NX}", real=True)
+    rp = tuple(rs) + sp.symbols(f"r{nx}:{WIDE_NX}", real=True)
+    dxp = sp.Matrix(list(dx) + [a - b for a, b in zip(sp_[nx:], rp[nx:])])
+    return xp, up, ps, fp, lp, lf, (sp_, rp, dxp)
 
 
 CODEGEN_VERSION = "2"   # part of the library key: bump when the printed C or the solver sources change meaning
@@ -238,8 +255,9 @@ CODEGEN_VERSION = "2"   # part of the library key: bump when the printed C or th
 
 def user_key(nx, nu, n_par, exprs):
     """Identity of a traced plant: dimensions and the canonical text of its three expressions."""
-    xs, us, ps, f, l, lf = exprs
-    text = "|".join([CODEGEN_VERSION, str(nx), str(nu), str(n_par), sp.srepr(f), sp.srepr(l), sp.srepr(lf)])
+    xs, us, ps, f, l, lf = exprs[:6]
+    text = "|".join([CODEGEN_VERSION, str(nx), str(nu), str(n_par), sp.srepr(f), sp.srepr(l), sp.srepr(lf)]
+                    + ([sp.srepr(exprs[6][2])] if len(exprs) > 6 else []))
     return hashlib.sha256(text.encode()).hexdigest()[:12]
 
 
@@ -251,7 +269,8 @@ def generate_user_header(nx, nu, n_par, exprs, name="user"):
     if wide:
         exprs = pad_wide(nx, nu, exprs)
         nx, nu = WIDE_NX, WIDE_NU
-    xs, us, ps, f, l, lf = exprs
+    xs, us, ps, f, l, lf = exprs[:6]
+    diff = exprs[6] if len(exprs) > 6 else None
     lx = sp.Matrix([l]).jacobian(xs)
     lu = sp.Matrix([l]).jacobian(us)
     lfx = sp.Matrix([lf]).jacobian(xs)
@@ -262,6 +281,8 @@ def generate_user_header(nx, nu, n_par, exprs, name="user"):
     out += f"#define USER_REAL_NX {real_nx}\n#define USER_REAL_NU {real_nu}\n"
     if wide:
         out += "#define USER_WIDE 1   /* stated with 12 states and 4 controls for the 16-lane backward kernel */\n"
+    if diff is not None:
+        out += "#define USER_HAS_DIFF 1   /* the plant's own CalcDifferentialState (model.py:22-23 overridden) */\n"
     out += "\n"
     parts = [
         ("user_gen_dynamics", ins, [("xn", f)], "x_next = discrete_dynamics(x, u)"),
@@ -272,6 +293,9 @@ def generate_user_header(nx, nu, n_par, exprs, name="user"):
          "stage derivatives: l_x l_u l_xx l_ux l_uu f_x f_u (row-major)"),
         ("user_gen_final", ins[:2], [("V_x", lfx), ("V_xx", lfx.jacobian(xs))], "final-cost derivatives"),
     ]
+    if diff is not None:
+        parts.append(("user_gen_diff_state", [("p", ps), ("s", diff[0]), ("r", diff[1])], [("dx", diff[2])],
+                      "CalcDifferentialState(state, ref_state)"))
     if wide:
         # what lane j of a team asks for: column j of [f_x f_u] as a directional derivative, and the cost terms of the
         # joint variable z = (x, u) in one piece

@@ -131,9 +131,14 @@ struct UserModel {
     {
         user_gen_final(par, x, Vx, Vxx);
     }
-    __device__ static void diff_state(const double*, const double* s, const double* r, double* dx)
+    __device__ static void diff_state(const double* par, const double* s, const double* r, double* dx)
     {
+#ifdef USER_HAS_DIFF
+        user_gen_diff_state(par, s, r, dx);      // the plant's own CalcDifferentialState
+#else
+        (void)par;
         diff_sub<NX>(s, r, dx);
+#endif
     }
 };
 #endif

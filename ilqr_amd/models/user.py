@@ -33,7 +33,9 @@ states and 4 controls (added states constant zero, added controls costing
 u^2/2 and moving nothing: the solve is that of the plant as written) and take the
 16-lanes-per-trajectory kernels of the quadrotors; arrays are widened on the
 way in and cut back on the way out, so the Python interface keeps the plant's
-own dimensions.  One parameter set per batch for those.
+own dimensions.  One parameter set per batch for those.  A plant that overrides
+CalcDifferentialState (same dimension as the state; e.g. an angle difference
+taken the short way round) has that method traced too.
 """
 from __future__ import annotations
 
@@ -60,6 +62,9 @@ class UserModel(Model):
             if getattr(cls, meth) is getattr(Model, meth):
                 raise TypeError(f"{cls.__name__} must define {meth} (README.md:25-31 of the reference)")
         self._user = (cls.discrete_dynamics, cls._cost_stage, cls._cost_final)
+        # the plant's own CalcDifferentialState (model.py:22-23 overridden), traced like the other three
+        self._user_diff = (cls.CalcDifferentialState
+                           if cls.CalcDifferentialState is not UserModel.CalcDifferentialState else None)
 
     # ------------------------------------------------------------ the user's own Python
     def python_dynamics(self, x, u):
@@ -89,8 +94,17 @@ class UserModel(Model):
     def trace(self):
         """(xs, us, ps, f, l, lf): the three methods run once on SymPy symbols."""
         from .. import codegen
+        diff = None
+        if self._user_diff is not None:
+            def diff(s, r, p):
+                saved = self.p
+                self.p = p
+                try:
+                    return self._user_diff(self, s, r)
+                finally:
+                    self.p = saved
         return codegen.user_expressions(self.nx, self.nu, self.p.shape[-1], self._traced(0), self._traced(1),
-                                        self._traced(2))
+                                        self._traced(2), diff)
 
     def header_text(self) -> str:
         from .. import codegen

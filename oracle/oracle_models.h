@@ -436,7 +436,11 @@ static double user_cost_final(const double *par, const double *x)
     user_gen_cost_final(par, x, &c);
     return c;
 }
+#ifdef USER_HAS_DIFF
+static void user_diff(const double *par, const double *s, const double *r, double *dx) { user_gen_diff_state(par, s, r, dx); }
+#else
 DEF_DIFF_SUB(user_diff, USER_NX)
+#endif
 #endif
 
 static const ilqr_oracle_model *oracle_model_table(int id)

@@ -72,7 +72,7 @@ def make_user_plant(spec):
     um = getattr(user_models, spec["cls"])(*spec.get("args", ()))
     key = (spec["cls"], tuple(um.p))
     if key not in _USER_FN:
-        xs, us, ps, f, l, lf = um.trace()
+        xs, us, ps, f, l, lf = um.trace()[:6]
         sub = dict(zip(ps, um.p))
         f, l, lf = f.subs(sub), l.subs(sub), lf.subs(sub)
         lx = sp.Matrix([l]).jacobian(xs); lu = sp.Matrix([l]).jacobian(us); lfx = sp.Matrix([lf]).jacobian(xs)
@@ -90,6 +90,12 @@ def make_user_plant(spec):
 
         def discrete_dynamics(self, x, u):
             return um.python_dynamics(x, u)
+
+        def CalcDifferentialState(self, state, ref_state):
+            if um._user_diff is None:
+                return Model.CalcDifferentialState(self, state, ref_state)
+            return np.asarray(um._user_diff(um, np.asarray(state, dtype=np.float64), np.asarray(ref_state, dtype=np.float64)),
+                              dtype=np.float64)
 
         def _cost_stage(self, x, u):
             return um.python_cost_stage(x, u)
@@ -549,6 +555,14 @@ def gen_user_tug(pool):
     run_cases("user_tug", dict(model="user", cls="Tug"), TUG_SP, x0, u0, pool)
 
 
+def gen_user_compass(pool):
+    """A plant defined by the user that overrides CalcDifferentialState (tests/user_models.py Compass)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from user_models import COMPASS_SP, compass_inputs
+    x0, u0 = compass_inputs(32, 11)
+    run_cases("user_compass", dict(model="user", cls="Compass"), COMPASS_SP, x0, u0, pool)
+
+
 def gen_quat_utils(pool):
     """Outputs of the reference's NumPy quaternion helpers (maths/quaternions.py) on random quaternions."""
     from maths import quaternions as rq
@@ -565,7 +579,7 @@ def gen_quat_utils(pool):
     print("[golden] quat_utils: 32 quaternions", flush=True)
 
 
-GENS = dict(quat_utils=gen_quat_utils, user_rover=gen_user_rover, user_tug=gen_user_tug, car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
+GENS = dict(quat_utils=gen_quat_utils, user_rover=gen_user_rover, user_tug=gen_user_tug, user_compass=gen_user_compass, car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
             acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat, baseline=gen_baseline_horizons, variants=gen_variants, units=gen_units)
 
 

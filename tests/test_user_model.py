@@ -15,7 +15,7 @@ import pytest
 
 from conftest import ROOT, load_golden
 from helpers import compare_to_golden, rel_traj
-from user_models import ROVER_SP, TUG_SP, Rover, Tug, rover_inputs, tug_inputs
+from user_models import COMPASS_SP, ROVER_SP, TUG_SP, Compass, Rover, Tug, compass_inputs, rover_inputs, tug_inputs
 
 
 @pytest.fixture(scope="module")
@@ -139,6 +139,46 @@ def test_widened_plant_solves_like_the_plant_as_written(oracle, tug_checker):
                           i["accepted"], i["regu_rounds"], J0=i["J0"], label="user_tug")
     assert n >= 28
     assert (g["regu_rounds"] > 0).all() and (g["ls_evals"] > 1).any()
+
+
+# ------------------------------------------------------------------- the plant's own CalcDifferentialState
+def test_overridden_differential_state_is_traced_and_matters(oracle, tmp_path_factory):
+    """Compass keeps its heading in (-pi, pi] and takes heading differences the short way round
+    (CalcDifferentialState overridden, control/models/model.py:22-23).  The reference's iLQR ran it as written
+    (tests/golden/user_compass.npz; 18 of the 32 solves cross the cut); the checker compiled with the traced override
+    reproduces that, and one compiled without it does not."""
+    g = load_golden("user_compass")
+    d = tmp_path_factory.mktemp("compass_hdr")
+    text = Compass().header_text()
+    assert "#define USER_HAS_DIFF 1" in text and "user_gen_diff_state" in text
+    (d / "user_gen.h").write_text(text)
+    chk = oracle.build_user(str(d), out_dir=str(d))
+    args = (int(g["N"]), int(g["max_iter"]), int(g["max_ls"]), float(g["d_tol"]), g["x0"], g["u_init"])
+    r = oracle.solve_batch("user", g["par"], *args, library=chk)
+    i = r["info"]
+    n = compare_to_golden(g, r["x"], r["u"], i["J_last"], i["iters"], i["status"], i["ls_evals"], i["accepted"],
+                          i["regu_rounds"], J0=i["J0"], label="user_compass")
+    assert n >= 28
+    crossing = (np.abs(np.diff(g["x"][:, :, 2], axis=1)) > 3).any(axis=1)
+    assert crossing.sum() >= 10
+
+    class PlainDiff(Compass):
+        CalcDifferentialState = Compass.__mro__[1].CalcDifferentialState     # UserModel's: state - ref_state
+
+    d2 = tmp_path_factory.mktemp("compass_plain_hdr")
+    text2 = PlainDiff().header_text()
+    assert "USER_HAS_DIFF" not in text2
+    (d2 / "user_gen.h").write_text(text2)
+    r2 = oracle.solve_batch("user", g["par"], *args, library=oracle.build_user(str(d2), out_dir=str(d2)))
+    differs = np.abs(r2["info"]["J_last"] - g["J_last"]) > 1e-6 * np.abs(g["J_last"])
+    assert differs[crossing].mean() > 0.5      # (others may differ too: iterates on the way crossed the cut)
+
+    class Shorter(Compass):
+        def CalcDifferentialState(self, state, ref_state):
+            return state[:2] - ref_state[:2]
+
+    with pytest.raises(NotImplementedError, match="Q_terms"):
+        Shorter().trace()
 
 
 # ----------------------------------------------------------------------------------------------- GPU
@@ -277,3 +317,23 @@ def test_wide_user_plant_batch_and_model_interface_on_gpu(oracle, tug_gpu):
     assert xt.shape == (6, 6) and np.allclose(xt[1], tug_gpu.python_dynamics(xs, us), rtol=1e-13, atol=1e-15)
     with pytest.raises(ValueError, match="one parameter set"):
         tug_gpu.set_params(np.zeros((4, 4)))
+
+
+@pytest.mark.gpu
+def test_overridden_differential_state_on_gpu_matches_reference_golden():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    plant = Compass()
+    plant.use_library(os.path.join(plant.library_dir(), "libilqr_user.so"))
+    g = load_golden("user_compass")
+    plant.set_params(g["par"])
+    sp = dict(N=int(g["N"]), max_iter=int(g["max_iter"]), max_ls=int(g["max_ls"]), d_tol=float(g["d_tol"]))
+    info, x, u = _solve(plant, sp, g["x0"], g["u_init"])
+    t = info.traces
+    n = compare_to_golden(g, x, u, info.J.cpu().numpy(), info.iters.cpu().numpy(), info.status.cpu().numpy(),
+                          t["ls_evals"].cpu().numpy(), t["accepted"].cpu().numpy(), info.regu_rounds.cpu().numpy(),
+                          J0=info.J0.cpu().numpy(), label="user_compass")
+    assert n >= 28
+    # the Python method is still the user's own
+    assert np.isclose(plant.CalcDifferentialState(np.array([0, 0, 3.0]), np.array([0, 0, -3.0]))[2], 6.0 - 2 * np.pi)

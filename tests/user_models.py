@@ -86,3 +86,47 @@ def tug_inputs(B, seed):
                           0.3 * rng.standard_normal((B, 3))])
     u0 = 0.2 * rng.standard_normal((B, TUG_SP["N"] - 1, 3))
     return x0, u0
+
+
+class Compass(UserModel):
+    """A unicycle whose heading state is kept in (-pi, pi] by the dynamics, with its own CalcDifferentialState
+    (control/models/model.py:22-23 overridden): the heading difference is taken the short way round, so a trajectory
+    that crosses the cut does not see a 2 pi jump in the feedback term K (x_new - x) of the forward pass.
+
+    x = [px, py, heading], u = [speed, turn rate], p = [goal_x, goal_y].
+    """
+    DT = 0.1
+
+    def __init__(self, goal=(-2.0, 0.5)):
+        super().__init__(nx=3, nu=2, params=list(goal), name="compass")
+
+    @staticmethod
+    def _wrap(a):
+        return m.atan2(m.sin(a), m.cos(a))
+
+    def discrete_dynamics(self, x, u):
+        h = self.DT
+        return m.array([x[0] + h * u[0] * m.cos(x[2]), x[1] + h * u[0] * m.sin(x[2]), self._wrap(x[2] + h * u[1])])
+
+    def CalcDifferentialState(self, state, ref_state):
+        return m.array([state[0] - ref_state[0], state[1] - ref_state[1], self._wrap(state[2] - ref_state[2])])
+
+    def _cost_stage(self, x, u):
+        goal = (x[0] - self.p[0]) ** 2 + (x[1] - self.p[1]) ** 2
+        return 0.1 * goal + 0.05 * u[0] ** 2 + 0.05 * u[1] ** 2
+
+    def _cost_final(self, x):
+        goal = (x[0] - self.p[0]) ** 2 + (x[1] - self.p[1]) ** 2
+        return 30.0 * goal
+
+
+COMPASS_SP = dict(N=40, max_iter=40, max_ls=20, d_tol=1e-3)
+
+
+def compass_inputs(B, seed):
+    """Starts heading roughly away from the goal (which lies towards -x): the turn takes the heading across +-pi."""
+    rng = np.random.default_rng(seed)
+    x0 = np.column_stack([rng.uniform(0, 1, B), rng.uniform(-1, 1, B), rng.uniform(2.2, 3.1, B) * rng.choice([-1, 1], B)])
+    u0 = np.column_stack([np.full(B, 1.0), rng.choice([-1.0, 1.0], B) * 1.5])[:, None, :] * np.ones((1, COMPASS_SP["N"] - 1, 1)) \
+        + 0.1 * rng.standard_normal((B, COMPASS_SP["N"] - 1, 2))
+    return x0, u0
