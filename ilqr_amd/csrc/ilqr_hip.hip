@@ -195,8 +195,6 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
     if (p->cost_N < 0 || p->cost_N > p->N) return fail(ILQR_E_BADARG, "cost_N must be 0 (= N) or within 1..N");
     if ((p->flags & ILQR_FLAG_LAPACK_EIGVALS) && d.ndx + d.nu > 8)
         return fail(ILQR_E_BADARG, "ILQR_FLAG_LAPACK_EIGVALS is built for the plants solved one trajectory per lane");
-    if ((p->flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY) && d.ndx + d.nu > 8 && d.npar <= 8)
-        return fail(ILQR_E_BADARG, "a user plant solved by the 16-lane kernels takes one parameter block for the batch");
     if ((p->flags & ILQR_FLAG_LS_SEQUENTIAL) && p->max_ls > 60)
         return fail(ILQR_E_BADARG, "ILQR_FLAG_LS_SEQUENTIAL supports max_ls <= 60");
     return ILQR_OK;

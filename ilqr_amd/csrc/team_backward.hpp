@@ -334,7 +334,10 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
     const int s = live ? s0 : a.count - 1;      // a team without a trajectory shadows the last one
     const int S = a.N - 1;
     const int id = a.idA[s];
-    const double* const par = PT ? a.par + (long)id * a.par_block : a.par;
+    // a small parameter block (user plants) is copied into registers, one per trajectory if the caller gave one per
+    // trajectory; a large one (weights and references) stays in memory, shared or per trajectory (PT)
+    const ParCache<M> par_regs = params_of<M, PT>(a, id);
+    const double* const par = par_regs.get();
     const RecIn T = slot_T<M>(a.TA, a.cap, s);
     double* const Gp = live ? a.G + (long)s * Rec<M>::RG : a.Gscratch;
     const long Gss = live ? a.cap * Rec<M>::RG : Rec<M>::RG;

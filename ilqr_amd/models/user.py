@@ -33,7 +33,7 @@ states and 4 controls (added states constant zero, added controls costing
 u^2/2 and moving nothing: the solve is that of the plant as written) and take the
 16-lanes-per-trajectory kernels of the quadrotors; arrays are widened on the
 way in and cut back on the way out, so the Python interface keeps the plant's
-own dimensions.  One parameter set per batch for those.  A plant that overrides
+own dimensions.  A plant that overrides
 CalcDifferentialState (same dimension as the state; e.g. an angle difference
 taken the short way round) has that method traced too.
 """
@@ -182,8 +182,6 @@ class UserModel(Model):
         trajectory of the batches solved from now on (batched goals; no rebuild either way)."""
         p = np.asarray(params, dtype=np.float64)
         n = self.p.shape[-1]
-        if p.ndim == 2 and self._wide():
-            raise ValueError("a plant with nx + nu > 8 takes one parameter set per batch")
         if p.ndim == 2 and p.shape[1] == n and n > 0:
             self.p = np.ascontiguousarray(p)
             return

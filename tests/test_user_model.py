@@ -315,8 +315,18 @@ def test_wide_user_plant_batch_and_model_interface_on_gpu(oracle, tug_gpu):
     assert np.allclose(fx, fd, rtol=1e-6, atol=1e-8)
     xt = tug_gpu.rollout(xs, np.tile(us, (5, 1)))
     assert xt.shape == (6, 6) and np.allclose(xt[1], tug_gpu.python_dynamics(xs, us), rtol=1e-13, atol=1e-15)
-    with pytest.raises(ValueError, match="one parameter set"):
-        tug_gpu.set_params(np.zeros((4, 4)))
+    # a goal and a keep-out disc per trajectory: every solve of the mixed batch equals, bit for bit, its solve in a
+    # batch that shares its parameters
+    goals = np.array([[1.5, -1.0, 0.6, -0.4], [2.0, 1.0, 1.0, 0.3], [-1.0, 2.0, -0.2, 0.9]])
+    which = rng.integers(0, 3, 96)
+    tug_gpu.set_params(goals[which])
+    infom, xm, um = _solve(tug_gpu, TUG_SP, x0[:96], u0[:96])
+    for k in range(3):
+        idx = np.where(which == k)[0]
+        tug_gpu.set_params(goals[k])
+        infos, xs_, us_ = _solve(tug_gpu, TUG_SP, x0[idx], u0[idx])
+        assert np.array_equal(xs_, xm[idx], equal_nan=True) and np.array_equal(us_, um[idx], equal_nan=True), k
+        assert np.array_equal(infos.iters.cpu().numpy(), infom.iters.cpu().numpy()[idx])
 
 
 @pytest.mark.gpu
