@@ -94,3 +94,50 @@ def test_hip_with_lapacks_rule_against_the_reference_population():
     r = BatchSolver(0, [2.0, 2.0], 40, 50, 20, 1e-3, flags=_lib.FLAG_LAPACK_EIGVALS).solve(x0, u0)
     cp = lambda t: t.cpu().numpy()
     _check(g, cp(r.iters), cp(r.status), cp(r.regu_rounds), cp(r.J), "hip, LAPACK's rule", True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The contract's second configuration: Acrobot2DModel N = 100, max_iter 20, max_linesearch_iters 10, random starts and
+# u_init ~ N(0, 1).  tests/golden/acrobot_population_ref.npz is the imported reference on the first 2048 of them
+# (tests/golden/make_population.py ... acrobot).  No stage of these solves regularises and |Q| stays below 1e6, so here
+# the solves are compared one by one: iteration count, exit, line-search evaluations, final cost (NaN where the
+# reference's is NaN: a third of these swing-ups diverge inside the horizon).
+def _acrobot():
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_population import ACROBOT_SP, acrobot_inputs
+    g = load_golden("acrobot_population_ref")
+    x0, u0 = acrobot_inputs(int(g["n"]), int(g["seed"]))
+    return g, x0, u0, ACROBOT_SP
+
+
+def _check_acrobot(g, iters, status, regu, ls_total, J, label):
+    same = (iters == g["iters"]) & (status == g["status"]) & (regu == g["regu_rounds"]) & (ls_total == g["ls_total"])
+    print(label, "ends like the reference: %.4f" % same.mean(), "exits", np.bincount(status, minlength=4),
+          "reference", np.bincount(g["status"], minlength=4), "mean iterations %.3f / %.3f" % (iters.mean(), g["iters"].mean()))
+    assert same.mean() >= 0.99, (label, same.mean())
+    with np.errstate(invalid="ignore"):
+        rel = np.abs(J - g["J"]) / np.abs(g["J"])
+    ok = (rel <= 1e-8) | (np.isnan(J) & np.isnan(g["J"]))
+    assert ok[same].mean() >= 0.995, (label, ok[same].mean())
+    assert np.abs(np.bincount(status, minlength=4) - np.bincount(g["status"], minlength=4)).max() <= 0.005 * len(iters)
+    assert abs(iters.mean() - g["iters"].mean()) < 0.002 * g["iters"].mean()
+
+
+def test_checker_against_the_reference_acrobot_population(oracle):
+    g, x0, u0, sp = _acrobot()
+    par = oracle.pack_quadratic(0.05, np.diag([1, 1, .1, .1]), 100.0 * np.eye(4), [[0.01]], [np.pi, 0, 0, 0], [0.0])
+    I = oracle.solve_batch("acrobot", par, sp["N"], sp["max_iter"], sp["max_ls"], sp["d_tol"], x0, u0)["info"]
+    _check_acrobot(g, I["iters"], I["status"], I["regu_rounds"], I["ls_total"], I["J_last"], "checker, acrobot")
+
+
+@pytest.mark.gpu
+def test_hip_against_the_reference_acrobot_population(oracle):
+    import torch
+    assert torch.cuda.is_available(), "this test needs a GPU"
+    from ilqr_amd.batch import BatchSolver
+    g, x0, u0, sp = _acrobot()
+    par = oracle.pack_quadratic(0.05, np.diag([1, 1, .1, .1]), 100.0 * np.eye(4), [[0.01]], [np.pi, 0, 0, 0], [0.0])
+    r = BatchSolver(1, par, sp["N"], sp["max_iter"], sp["max_ls"], sp["d_tol"]).solve(x0, u0)
+    cp = lambda t: t.cpu().numpy()
+    _check_acrobot(g, cp(r.iters), cp(r.status), cp(r.regu_rounds), cp(r.ls_total), cp(r.J), "hip, acrobot")
