@@ -31,3 +31,7 @@ void eigr_eigvals_many(long count, int n, const double *a, double *wr, double *w
 {
     for (long c = 0; c < count; ++c) rc[c] = eigr_eigvals(n, a + c * n * n, wr + c * n, wi + c * n);
 }
+
+/* the DGEMV restatements on their own (column-major A [m x n], lda): y = A'x and y = Ax */
+void eigr_gemv_t(int m, int n, const double *a, int lda, const double *x, double *y) { eig_gemv_t(m, n, a, lda, x, y); }
+void eigr_gemv_n(int m, int n, const double *a, int lda, const double *x, double *y) { eig_gemv_n(m, n, a, lda, x, y); }

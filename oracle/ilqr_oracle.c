@@ -57,7 +57,7 @@ static void matTmul(const double *A, const double *B, double *C, int k, int m, i
     for (int i = 0; i < m; ++i)
         for (int j = 0; j < n; ++j) {
             double s = 0.0;
-            for (int t = 0; t < k; ++t) s += A[t * m + i] * B[t * n + j];
+            for (int t = 0; t < k; ++t) s = fma(A[t * m + i], B[t * n + j], s);
             C[i * n + j] = s;
         }
 }
@@ -67,7 +67,7 @@ static void matmul(const double *A, const double *B, double *C, int m, int k, in
     for (int i = 0; i < m; ++i)
         for (int j = 0; j < n; ++j) {
             double s = 0.0;
-            for (int t = 0; t < k; ++t) s += A[i * k + t] * B[t * n + j];
+            for (int t = 0; t < k; ++t) s = fma(A[i * k + t], B[t * n + j], s);
             C[i * n + j] = s;
         }
 }
