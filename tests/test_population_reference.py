@@ -151,10 +151,10 @@ def test_hip_against_the_reference_acrobot_population(oracle):
 # regularisation rounds per solve: stages whose Q(r) is dominated by the rank-deficient 2^r P, where LAPACK's verdict
 # is rounding noise), so nothing is compared solve by solve: these tests record how far the populations are apart.
 #   reference        EA   exits dJ<1 / max_iter / LinAlgError    2 / 674 / 348   mean iterations 13.35   rounds 29 700
-#   checker, LAPACK                                             2 / 568 / 454                    11.65          25 600
+#   checker, LAPACK                                             1 / 563 / 460                    11.57          25 300
 #   checker LDL', GPU                                          50 / 804 / 170                    16.38          60 600
 #   reference        quat                                      16 / 850 / 158                    16.95          13 500
-#   checker, LAPACK                                            10 / 814 / 200                    16.36          13 100
+#   checker, LAPACK                                             7 / 823 / 194                    16.51          12 900
 #   checker LDL', GPU                                          48 / 976 /   0                    19.63          38 500
 # With LAPACK's rule restated the checker's population is the reference's to a few per cent for the quaternion plant
 # and to 10 % of the batch for the Euler-angle plant (what is left is the rounding of the matrix products that form Q and
