@@ -156,6 +156,30 @@ struct QPack {
 // (control/models/model.py:45-53), in the reference's order of operations:
 // Q_xx = l_xx + (f_x' V_xx) f_x, Q_ux = l_ux + (f_u' V_xx) f_x, Q_uu = l_uu + (f_u' V_xx) f_u.
 // aux = [fx (n*n), fu (n*m)].
+// P = (0.1 [fx fu])'[fx fu]: lower triangle PL (packed by rows) and the entries PU above the diagonal of the xx and uu
+// blocks, each entry (i, j) = sum over t ascending of fma(0.1 F[t][i], F[t][j], .)   (iLQRController.py:111-113)
+template <int n, int m>
+__device__ __forceinline__ void exact_p(const double* fx, const double* fu, double* PL, double* PU)
+{
+    constexpr int w = n + m;
+#pragma unroll
+    for (int i = 0; i < w; ++i)
+#pragma unroll
+        for (int j = 0; j < w; ++j) {
+            if (i < j && (i < n) != (j < n)) continue;      // upper right block: the mirror image of Q_ux, exactly
+            double s = 0.0;
+#pragma unroll
+            for (int t = 0; t < n; ++t) {
+                const double a = (i < n) ? fx[t * n + i] : fu[t * m + (i - n)];
+                const double b = (j < n) ? fx[t * n + j] : fu[t * m + (j - n)];
+                s = __builtin_fma(0.1 * a, b, s);
+            }
+            if (i >= j) PL[tri(i, j)] = s;
+            else if (j < n) PU[upp(n, i, j)] = s;
+            else PU[upp(m, i - n, j - n, QPack<n, m>::UUB)] = s;
+        }
+}
+
 template <class M>
 struct DenseTerms {
     static constexpr int n = M::NDX, m = M::NU, w = n + m;
@@ -257,6 +281,15 @@ struct DenseTerms {
                 PL[tri(i, j)] = s;
             }
     }
+    // The same with the entries above the diagonal of the xx and uu blocks as the reference has them: its
+    // (0.1 f)'f is a matrix product of two different arrays, so entry (i, j) sums (0.1 f[t][i]) f[t][j] and its
+    // mirror image (0.1 f[t][j]) f[t][i]: equal up to rounding, and in stages that regularisation cannot rescue
+    // (Q(r) dominated by 2^r P) that rounding is what LAPACK's verdict is made of.  Ascending t with fused
+    // multiply-adds from zero is NumPy's `@` bit for bit.
+    __device__ static void regu_p_exact(const double* aux, double* PL, double* PU)
+    {
+        exact_p<n, m>(aux, aux + n * n, PL, PU);
+    }
     __device__ static void final_full(const double* par, const double* x, double* Vx, double* V)
     {
         M::final(par, x, Vx, V);
@@ -273,6 +306,19 @@ struct CarSparseTerms {
         car_gen_backward_terms(par, x, u, Vx, V, Qx, Qu, QL, QU, aux);
     }
     __device__ static void regu_p(const double* aux, double* PL) { car_gen_regu_p(aux, PL); }
+    // (see DenseTerms::regu_p_exact)  f_x = I + the six entries in aux, f_u = dt at (3, 0) and (4, 1)  (car.py:76-79)
+    __device__ static void regu_p_exact(const double* aux, double* PL, double* PU)
+    {
+        double fx[25], fu[10];
+#pragma unroll
+        for (int e = 0; e < 25; ++e) fx[e] = (e / 5 == e % 5) ? 1.0 : 0.0;
+#pragma unroll
+        for (int e = 0; e < 10; ++e) fu[e] = 0.0;
+        fx[0 * 5 + 2] = aux[0]; fx[0 * 5 + 3] = aux[1]; fx[1 * 5 + 2] = aux[2]; fx[1 * 5 + 3] = aux[3];
+        fx[2 * 5 + 3] = aux[4]; fx[2 * 5 + 4] = aux[5];
+        fu[3 * 2 + 0] = 0.1; fu[4 * 2 + 1] = 0.1;
+        exact_p<5, 2>(fx, fu, PL, PU);
+    }
     __device__ static void final_full(const double* par, const double* x, double* Vx, double* V)
     {
         car_gen_final(par, x, Vx, V);
@@ -388,7 +434,7 @@ constexpr int stage_lds_doubles() { return scan_lds_doubles<n, m>() + 64 * (QPac
 template <int n, int m>
 constexpr int exact_lds_doubles()
 {
-    return ((n + m) * (n + m) + 2 * (n + m)) * 64 + (REGU_GROUPS * QPack<n, m>::NUP + 1) / 2 * 2;
+    return ((n + m) * (n + m) + 2 * (n + m)) * 64 + 2 * ((REGU_GROUPS * QPack<n, m>::NUP + 1) / 2 * 2);
 }
 // the lane's matrix for eig::Lane from the packed lower triangle L and the upper entries U of Qxx and Quu
 // (the Qux block is one block: its mirror image fills the upper right corner, as _full_hessian does, :139-147)
@@ -408,20 +454,6 @@ __device__ __forceinline__ void fill_full(const eig::Lane<n + m, 64>& E, const d
             else v = L[tri(j, i)];
             E.A(i + 1, j + 1) = v;
         }
-}
-// position in the lower triangle of P of the mirror image of upper entry e of QU
-template <int n, int m>
-__device__ __forceinline__ constexpr int mirror_of_upper(int e)
-{
-    using QP = QPack<n, m>;
-    int k = 0;
-    for (int i = 0; i < n; ++i)
-        for (int j = i + 1; j < n; ++j, ++k)
-            if (k == e) return tri(j, i);
-    for (int i = 0; i < m; ++i)
-        for (int j = i + 1; j < m; ++j, ++k)
-            if (k == e) return tri(n + j, n + i);
-    return 0;
 }
 // largest |entry| of a packed lower triangle joined to mq (a NaN entry never wins)
 template <int NL>
@@ -488,7 +520,9 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
     // EXACT: the lane's matrix and work space for the LAPACK path, and the published trajectories' upper entries
     double* const exact0 = lds + stage_lds_doubles<n, m, TermsOf<M>::type::AUX>();
     const eig::Lane<w, 64> E{exact0 + lane, exact0 + w * w * 64 + lane};
-    double* const ldsQU = exact0 + (w * w + 2 * w) * 64;
+    double* const ldsQU = exact0 + (w * w + 2 * w) * 64;                                  // Q(0) above the diagonal
+    double* const ldsPU = ldsQU + (REGU_GROUPS * (NUP > 0 ? NUP : 1) + 1) / 2 * 2;          // P above the diagonal
+    double PUown[NUP > 0 ? NUP : 1];       // EXACT: this lane's own P above the diagonal, for the accepted round
     {
         double aux[TR::AUX];
         TR::backward_terms(par, xk, uk, Vx, V, Qx, Qu, QL, QU, aux);
@@ -537,13 +571,17 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
             double PL[NL], aux[TR::AUX];
             ILQR_UNROLL
             for (int e = 0; e < TR::AUX; ++e) aux[e] = park[(NL + e) * 64];
-            TR::regu_p(aux, PL);
+            if constexpr (EXACT) TR::regu_p_exact(aux, PL, PUown);
+            else TR::regu_p(aux, PL);
             ILQR_UNROLL
             for (int e = 0; e < NL; ++e) ldsP[rank * NL + e] = PL[e];
             srcs[rank] = lane;
             if constexpr (EXACT) {
                 ILQR_UNROLL
-                for (int e = 0; e < NUP; ++e) ldsQU[rank * NUP + e] = QU[e];
+                for (int e = 0; e < NUP; ++e) {
+                    ldsQU[rank * NUP + e] = QU[e];
+                    ldsPU[rank * NUP + e] = PUown[e];
+                }
             }
         }
         wave_sync();
@@ -556,7 +594,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
                 double U[NUP > 0 ? NUP : 1];
                 ILQR_UNROLL
                 for (int e = 0; e < NUP; ++e)
-                    U[e] = __builtin_fma(regu_coef(c + 1), ldsP[g * NL + mirror_of_upper<n, m>(e)], ldsQU[g * NUP + e]);
+                    U[e] = __builtin_fma(regu_coef(c + 1), ldsPU[g * NUP + e], ldsQU[g * NUP + e]);
                 mq = max_abs_packed<NL>(L, mq);
                 fill_full<n, m>(E, L, U);
                 t = E.has_negative();
@@ -593,17 +631,22 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
                 ILQR_PHASE_BARRIER();
                 ILQR_UNROLL
                 for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(coef, pe[e], q0[e]);
-                // the entries above the diagonal get the mirrored entries of P (P is symmetric)
-                ILQR_UNROLL
-                for (int i = 0; i < n; ++i)
+                if constexpr (EXACT) {
                     ILQR_UNROLL
-                    for (int j = i + 1; j < n; ++j)
-                        QU[upp(n, i, j)] = __builtin_fma(coef, pl[tri(j, i)], QU[upp(n, i, j)]);
-                ILQR_UNROLL
-                for (int i = 0; i < m; ++i)
+                    for (int e = 0; e < NUP; ++e) QU[e] = __builtin_fma(coef, PUown[e], QU[e]);
+                } else {
+                    // the entries above the diagonal get the mirrored entries of P (P is symmetric up to rounding)
                     ILQR_UNROLL
-                    for (int j = i + 1; j < m; ++j)
-                        QU[upp(m, i, j, QP::UUB)] = __builtin_fma(coef, pl[tri(n + j, n + i)], QU[upp(m, i, j, QP::UUB)]);
+                    for (int i = 0; i < n; ++i)
+                        ILQR_UNROLL
+                        for (int j = i + 1; j < n; ++j)
+                            QU[upp(n, i, j)] = __builtin_fma(coef, pl[tri(j, i)], QU[upp(n, i, j)]);
+                    ILQR_UNROLL
+                    for (int i = 0; i < m; ++i)
+                        ILQR_UNROLL
+                        for (int j = i + 1; j < m; ++j)
+                            QU[upp(m, i, j, QP::UUB)] = __builtin_fma(coef, pl[tri(n + j, n + i)], QU[upp(m, i, j, QP::UUB)]);
+                }
                 ok = ok && (tt >= 0);
             } else {
                 stuck_here = true;      // Q(0) stays in the park: the stuck scan builds every round from it
@@ -623,12 +666,16 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
             double PL[NL], aux[TR::AUX];
             ILQR_UNROLL
             for (int e = 0; e < TR::AUX; ++e) aux[e] = park[(NL + e) * 64];
-            TR::regu_p(aux, PL);
+            if constexpr (EXACT) TR::regu_p_exact(aux, PL, PUown);
+            else TR::regu_p(aux, PL);
             ILQR_UNROLL
             for (int e = 0; e < NL; ++e) ldsP[e] = PL[e];
             if constexpr (EXACT) {
                 ILQR_UNROLL
-                for (int e = 0; e < NUP; ++e) ldsQU[e] = QU[e];
+                for (int e = 0; e < NUP; ++e) {
+                    ldsQU[e] = QU[e];
+                    ldsPU[e] = PUown[e];
+                }
             }
         }
         for (int base = REGU_BASE + 1;; base += 64) {
@@ -641,7 +688,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
                 double U[NUP > 0 ? NUP : 1];
                 ILQR_UNROLL
                 for (int e = 0; e < NUP; ++e)
-                    U[e] = __builtin_fma(regu_coef(base + lane), ldsP[mirror_of_upper<n, m>(e)], ldsQU[e]);
+                    U[e] = __builtin_fma(regu_coef(base + lane), ldsPU[e], ldsQU[e]);
                 mq = max_abs_packed<NL>(L, mq);
                 fill_full<n, m>(E, L, U);
                 t = E.has_negative();
@@ -665,16 +712,21 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
                     ILQR_PHASE_BARRIER();
                     ILQR_UNROLL
                     for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(cw, pe[e], q0[e]);
-                    ILQR_UNROLL
-                    for (int i = 0; i < n; ++i)
+                    if constexpr (EXACT) {
                         ILQR_UNROLL
-                        for (int j = i + 1; j < n; ++j)
-                            QU[upp(n, i, j)] = __builtin_fma(cw, ldsP[tri(j, i)], QU[upp(n, i, j)]);
-                    ILQR_UNROLL
-                    for (int i = 0; i < m; ++i)
+                        for (int e = 0; e < NUP; ++e) QU[e] = __builtin_fma(cw, PUown[e], QU[e]);
+                    } else {
                         ILQR_UNROLL
-                        for (int j = i + 1; j < m; ++j)
-                            QU[upp(m, i, j, QP::UUB)] = __builtin_fma(cw, ldsP[tri(n + j, n + i)], QU[upp(m, i, j, QP::UUB)]);
+                        for (int i = 0; i < n; ++i)
+                            ILQR_UNROLL
+                            for (int j = i + 1; j < n; ++j)
+                                QU[upp(n, i, j)] = __builtin_fma(cw, ldsP[tri(j, i)], QU[upp(n, i, j)]);
+                        ILQR_UNROLL
+                        for (int i = 0; i < m; ++i)
+                            ILQR_UNROLL
+                            for (int j = i + 1; j < m; ++j)
+                                QU[upp(m, i, j, QP::UUB)] = __builtin_fma(cw, ldsP[tri(n + j, n + i)], QU[upp(m, i, j, QP::UUB)]);
+                    }
                     ok = ok && (tw >= 0);
                     maxq = fmax(maxq, mqw);
                 }
