@@ -121,8 +121,17 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
         HIP_TRY(hipMemsetAsync(a.cnt, 0, 64 * sizeof(int32_t), st));
         tm.begin(ILQR_PHASE_BACKWARD);
         if constexpr (M::TEAM_BACKWARD) {
-            hipLaunchKernelGGL((pipe_backward_team_kernel<M, PT>), dim3(blocks_for(count, PIPE_WG / TEAM_LANES)),
-                               dim3(PIPE_WG), 0, st, a);
+            if constexpr (team_exact_built<M, PT>()) {
+                if (a.flags & ILQR_FLAG_LAPACK_EIGVALS)
+                    hipLaunchKernelGGL((pipe_backward_team_kernel<M, false, true>), dim3(blocks_for(count, PIPE_WG / TEAM_LANES)),
+                                       dim3(PIPE_WG), 0, st, a);
+                else
+                    hipLaunchKernelGGL((pipe_backward_team_kernel<M, PT>), dim3(blocks_for(count, PIPE_WG / TEAM_LANES)),
+                                       dim3(PIPE_WG), 0, st, a);
+            } else {
+                hipLaunchKernelGGL((pipe_backward_team_kernel<M, PT>), dim3(blocks_for(count, PIPE_WG / TEAM_LANES)),
+                                   dim3(PIPE_WG), 0, st, a);
+            }
         } else if (a.flags & ILQR_FLAG_LAPACK_EIGVALS) {
             hipLaunchKernelGGL((pipe_backward_kernel<M, PT, true>), dim3(blocks_for(count, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
         } else {

@@ -18,6 +18,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "solve_pipeline.hpp"
 
 namespace ilqr {
@@ -314,8 +316,195 @@ struct TeamOps<UserModel> {
 };
 #endif
 
+// ------------------------------------------------------------------
+// ILQR_FLAG_LAPACK_EIGVALS for the 16-lanes-per-trajectory kernel: the loop of iLQRController.py:106-115 with every
+// test made the way NumPy makes it (eig_device.hpp: DGEEV restated) on the full 16 x 16 matrix, one matrix per lane.
+// A team's lanes hold the rows of Q and of P = (0.1 F)'F; they are published in LDS, the upper right block as the
+// mirror image of the lower left one (the reference assembles Q from Q_xx, Q_ux, Q_uu, :139-147), and then
+//   trip 0: lane 8 t + c tests round c of team t (c = 0..7),
+//   a team still failing is scanned 32 rounds per trip, lane l testing round base + l,
+// round r being the reference's running sum Q(r) = Q(r - 1) + 2^(r-1) P (r rounded additions, not one product).
+// LDS: 32 matrices with their work space, the four teams' Q(0) and P, two checkpoints of the running sum.
+// ------------------------------------------------------------------
+constexpr int TX_LANES = 32;
+constexpr int TX_EIG = (16 * 16 + 2 * 16) * TX_LANES;
+constexpr int TX_PUB = (PIPE_WG / TEAM_LANES) * 2 * 256;
+constexpr int TEAM_EXACT_LDS = TX_EIG + TX_PUB + 2 * 256;
+
+// the lane's matrix: q + (2^k0 + ... + 2^(k0 + nr - 1)) p, added one term after the other; q, p row-major 16 x 16
+__device__ __forceinline__ void team_exact_build(const eig::Lane<16, TX_LANES>& E, const double* q, const double* p,
+                                                 int k0, int nr, double& mq)
+{
+#pragma clang fp contract(off)
+#pragma unroll 1
+    for (int e = 0; e < 256; ++e) {
+        double s = q[e];
+        const double pe = p[e];
+        for (int i = 0; i < nr; ++i) s += ldexp(pe, k0 + i);
+        const double as = __builtin_fabs(s);
+        mq = (as > mq) ? as : mq;
+        E.a[((e >> 4) + (e & 15) * 16) * TX_LANES] = s;
+    }
+}
+
+// Qrow, Prow: row j of the team's Q(0) and P (in: as computed; out: Q(r), and P with the mirrored block).
+// r: rounds taken; verdict: the last test's (0 = accepted, -1 = NumPy raises LinAlgError).  All 64 lanes call together.
+__device__ __forceinline__ void team_regularise_exact(double* Qrow, double* Prow, int lane, int team, int j, bool alive,
+                                                      double* X, int& r, int& verdict, double& maxq)
+{
+#pragma clang fp contract(off)
+    constexpr int n = 12, m = 4, w = 16;
+    const eig::Lane<16, TX_LANES> E{X + (lane & (TX_LANES - 1)), X + 256 * TX_LANES + (lane & (TX_LANES - 1))};
+    double* const pubQ = X + TX_EIG;
+    double* const pubP = pubQ + (PIPE_WG / TEAM_LANES) * 256;
+    double* ck = X + TX_EIG + TX_PUB;
+    double* ckn = ck + 256;
+    double* const myQ = pubQ + team * 256;
+    double* const myP = pubP + team * 256;
+    wave_sync();
+#pragma unroll
+    for (int c = 0; c < w; ++c) {
+        myQ[j * w + c] = Qrow[c];
+        myP[j * w + c] = Prow[c];
+    }
+    wave_sync();
+    if (j < n) {
+#pragma unroll
+        for (int b = 0; b < m; ++b) {
+            Qrow[n + b] = myQ[(n + b) * w + j];
+            Prow[n + b] = myP[(n + b) * w + j];
+        }
+#pragma unroll
+        for (int b = 0; b < m; ++b) {
+            myQ[j * w + n + b] = Qrow[n + b];
+            myP[j * w + n + b] = Prow[n + b];
+        }
+    }
+    wave_sync();
+
+    // ---- trip 0: rounds 0..7 of the four teams
+    bool stuck = false;
+    {
+        int t = 1;
+        double mq = 0.0;
+        const int tt = (lane >> 3) & 3, c = lane & 7;
+        if (lane < TX_LANES) {
+            team_exact_build(E, pubQ + tt * 256, pubP + tt * 256, 0, c, mq);
+            t = E.has_negative();
+        }
+        const unsigned long long passed = __ballot(lane < TX_LANES && t != 1);
+        const int byte = (int)((passed >> (8 * team)) & 0xFFull);
+        const int cstar = byte ? __ffs(byte) - 1 : -1;
+        const int lim = (cstar >= 0) ? cstar : 7;
+        const int tv = __shfl(t, 8 * team + lim);
+        double mqt = 0.0;
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) {
+            const double v = __shfl(mq, 8 * team + c2);
+            mqt = (c2 <= lim && v > mqt) ? v : mqt;
+        }
+        if (alive) {
+            maxq = (mqt > maxq) ? mqt : maxq;
+            r = (cstar >= 0) ? cstar : 8;
+            verdict = tv;
+            stuck = cstar < 0;
+        } else {
+            r = 0;
+            verdict = 0;
+        }
+    }
+    if (!stuck && r > 0) {
+#pragma unroll
+        for (int c = 0; c < w; ++c) {
+            double s = Qrow[c];
+            for (int k = 0; k < r; ++k) s += ldexp(Prow[c], k);
+            Qrow[c] = s;
+        }
+    }
+
+    // ---- teams still failing after round 7, one after the other, 32 rounds per trip
+    unsigned long long todo = __ballot(stuck);
+#pragma unroll 1
+    while (todo) {
+        const int tq = (__ffsll((long long)todo) - 1) >> 4;
+        todo &= ~(0xFFFFull << (16 * tq));
+        const double* const q0 = pubQ + tq * 256;
+        const double* const pp = pubP + tq * 256;
+        wave_sync();
+        for (int e = lane; e < 256; e += 64) {       // checkpoint: the sum after 8 rounds
+            double s = q0[e];
+            for (int k = 0; k < 8; ++k) s += ldexp(pp[e], k);
+            ck[e] = s;
+        }
+        double mqs = 0.0;
+#pragma unroll 1
+        for (int base = 8;; base += TX_LANES) {
+            wave_sync();
+            int t = 1;
+            double mq = 0.0;
+            if (lane < TX_LANES) {
+                team_exact_build(E, ck, pp, base, lane, mq);
+                t = E.has_negative();
+            }
+            const unsigned long long stops = __ballot(lane < TX_LANES && t != 1);
+            const int win = stops ? __ffsll((long long)stops) - 1 : TX_LANES - 1;
+            double v = (lane <= win) ? mq : 0.0;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt *= 2) {
+                const double o = __shfl_xor(v, dlt);
+                v = (o > v) ? o : v;
+            }
+            mqs = (v > mqs) ? v : mqs;
+            if (stops) {
+                const int tw = __shfl(t, win);
+                // the accepted matrix goes back to the team's rows: built again (the test destroyed it) in Q(0)'s place
+                if (lane == win) {
+#pragma unroll 1
+                    for (int e = 0; e < 256; ++e) {
+                        double s = ck[e];
+                        for (int i = 0; i < win; ++i) s += ldexp(pp[e], base + i);
+                        pubQ[tq * 256 + e] = s;
+                    }
+                }
+                wave_sync();
+                if (team == tq) {
+                    r = base + win;
+                    verdict = tw;
+#pragma unroll
+                    for (int c = 0; c < w; ++c) Qrow[c] = q0[j * w + c];
+                }
+                break;
+            }
+            if (base + TX_LANES > TEAM_REGU_MAX) {      // 0.1 * 2^r overflowed long before: cannot happen, but never spin
+                if (team == tq) {
+                    r = base + TX_LANES;
+                    verdict = -1;
+                }
+                break;
+            }
+            for (int e = lane; e < 256; e += 64) {       // next checkpoint: 32 rounds further
+                double s = ck[e];
+                for (int i = 0; i < TX_LANES; ++i) s += ldexp(pp[e], base + i);
+                ckn[e] = s;
+            }
+            double* const sw = ck;
+            ck = ckn;
+            ckn = sw;
+        }
+        if (team == tq) maxq = (mqs > maxq) ? mqs : maxq;
+    }
+}
+
+// The exact kernel is built for the two quadrotor plants with one parameter block for the batch.
+template <class M, bool PT>
+constexpr bool team_exact_built()
+{
+    return !PT && (std::is_same_v<M, QuadEAModel> || std::is_same_v<M, QuadQuatModel>);
+}
+
 // PT: one parameter block per trajectory (at a.par + id * a.par_block) instead of one for all.
-template <class M, bool PT = false>
+// EXACT: ILQR_FLAG_LAPACK_EIGVALS (team_regularise_exact above).
+template <class M, bool PT = false, bool EXACT = false>
 __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
 {
     using OPS = TeamOps<M>;
@@ -325,6 +514,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
     constexpr int TEAM_ALL = TEAM_LDS + OPS::EXTRA;
     __shared__ double lds_all[(PIPE_WG / TEAM_LANES) * TEAM_ALL];
     __shared__ double shared_all[OPS::SHARED > 0 ? (PT ? PIPE_WG / TEAM_LANES : 1) * OPS::SHARED : 1];
+    __shared__ double exact_all[EXACT ? TEAM_EXACT_LDS : 1];
     const int lane = threadIdx.x & 63, team = lane / TEAM_LANES, j = lane % TEAM_LANES;
     const unsigned long long tmask = 0xFFFFull << (team * TEAM_LANES);
     double* const L = lds_all + team * TEAM_ALL;
@@ -423,40 +613,48 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
         // needs more (entries of Q around 1e200 can take a thousand doublings) is searched by doubling r until
         // the test stops failing and bisecting back to the first such r: the same answer as the one-by-one
         // scan whenever "has a negative eigenvalue" does not switch back on as r grows, in ~20 tests.
-        int r_lo = -1, r_hi = -1, neg_hi = 0;          // last failing round, first known stopping round
-        bool testing = true;
+        if constexpr (EXACT) {
+            int r = 0, verdict = 0;
+            team_regularise_exact(Qrow, Prow, lane, team, j, alive, exact_all, r, verdict, maxq);
+            ok = ok && (verdict >= 0);
+            if (alive && r > 0) rs += 1;
+            rr += r;
+        } else {
+            int r_lo = -1, r_hi = -1, neg_hi = 0;          // last failing round, first known stopping round
+            bool testing = true;
 #pragma unroll 1
-        while (__ballot(testing) != 0ull) {
-            int rt;
-            if (r_hi < 0) rt = (r_lo < TEAM_REGU_LINEAR) ? r_lo + 1 : min(2 * r_lo, TEAM_REGU_MAX);
-            else rt = (r_lo + r_hi) / 2;
-            const double coef = regu_coef(rt);
-            double Lr[w - 1];
+            while (__ballot(testing) != 0ull) {
+                int rt;
+                if (r_hi < 0) rt = (r_lo < TEAM_REGU_LINEAR) ? r_lo + 1 : min(2 * r_lo, TEAM_REGU_MAX);
+                else rt = (r_lo + r_hi) / 2;
+                const double coef = regu_coef(rt);
+                double Lr[w - 1];
 #pragma unroll
-            for (int c = 0; c < w - 1; ++c) Lr[c] = (rt == 0) ? Qrow[c] : __builtin_fma(coef, Prow[c], Qrow[c]);
-            const double dg = (rt == 0) ? qdiag : __builtin_fma(coef, pdiag, qdiag);
-            double mqt = maxq;
-            const int neg = team_has_negative_eig(Lr, dg, j, tmask, L + tl::COL, mqt);
-            if (testing) {
-                maxq = mqt;
-                if (alive && neg == 1 && rt < TEAM_REGU_MAX) {
-                    r_lo = rt;
-                } else {
-                    r_hi = rt;
-                    neg_hi = (alive && neg == 1) ? -1 : neg;     // still negative at the cap: 0.1 * 2^r overflowed long ago
+                for (int c = 0; c < w - 1; ++c) Lr[c] = (rt == 0) ? Qrow[c] : __builtin_fma(coef, Prow[c], Qrow[c]);
+                const double dg = (rt == 0) ? qdiag : __builtin_fma(coef, pdiag, qdiag);
+                double mqt = maxq;
+                const int neg = team_has_negative_eig(Lr, dg, j, tmask, L + tl::COL, mqt);
+                if (testing) {
+                    maxq = mqt;
+                    if (alive && neg == 1 && rt < TEAM_REGU_MAX) {
+                        r_lo = rt;
+                    } else {
+                        r_hi = rt;
+                        neg_hi = (alive && neg == 1) ? -1 : neg;     // still negative at the cap: 0.1 * 2^r overflowed long ago
+                    }
+                    testing = (r_hi < 0) || (r_hi - r_lo > 1);
                 }
-                testing = (r_hi < 0) || (r_hi - r_lo > 1);
             }
-        }
-        const int r = r_hi;
-        ok = ok && (neg_hi >= 0);
-        if (alive && r > 0) rs += 1;
-        if (r > 0) {
-            const double coef = regu_coef(r);
+            const int r = r_hi;
+            ok = ok && (neg_hi >= 0);
+            if (alive && r > 0) rs += 1;
+            if (r > 0) {
+                const double coef = regu_coef(r);
 #pragma unroll
-            for (int c = 0; c < w; ++c) Qrow[c] = __builtin_fma(coef, Prow[c], Qrow[c]);
+                for (int c = 0; c < w; ++c) Qrow[c] = __builtin_fma(coef, Prow[c], Qrow[c]);
+            }
+            rr += r;
         }
-        rr += r;
 
         // ---- gains (:125-129)
         wave_sync();

@@ -361,18 +361,18 @@ static int backward_pass(const ilqr_oracle_model *M, const double *par, const do
                 for (int i = 0; i < n; ++i)
                     for (int j = 0; j < n; ++j) {
                         double s = 0.0;
-                        for (int t = 0; t < n; ++t) s += (0.1 * fx[t * n + i]) * fx[t * n + j];
+                        for (int t = 0; t < n; ++t) s = fma(0.1 * fx[t * n + i], fx[t * n + j], s);
                         Pxx[i * n + j] = s;
                     }
                 for (int i = 0; i < nu; ++i) {
                     for (int j = 0; j < nu; ++j) {
                         double s = 0.0;
-                        for (int t = 0; t < n; ++t) s += (0.1 * fu[t * nu + i]) * fu[t * nu + j];
+                        for (int t = 0; t < n; ++t) s = fma(0.1 * fu[t * nu + i], fu[t * nu + j], s);
                         Puu[i * nu + j] = s;
                     }
                     for (int j = 0; j < n; ++j) {
                         double s = 0.0;
-                        for (int t = 0; t < n; ++t) s += (0.1 * fu[t * nu + i]) * fx[t * n + j];
+                        for (int t = 0; t < n; ++t) s = fma(0.1 * fu[t * nu + i], fx[t * n + j], s);
                         Pux[i * n + j] = s;
                     }
                 }

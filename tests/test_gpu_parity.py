@@ -613,6 +613,36 @@ def test_lapack_eigvals_flag_reproduces_the_reference_at_long_horizons(torch_gpu
         assert n >= min_compared(name, g)
 
 
+def test_lapack_eigvals_flag_on_the_quadrotor_fixtures(torch_gpu, oracle):
+    """ILQR_FLAG_LAPACK_EIGVALS in the 16-lanes-per-trajectory kernel.  On the reproducible fixtures the decisions are
+    the reference's one by one, as with the default rule; on the contract's configurations 3 and 4 far from hover
+    (status-class fixtures, 16 solves each) the exits are compared with the reference's as classes, and a per-trajectory
+    parameter block with the flag is refused."""
+    from ilqr_amd import _lib
+    from ilqr_amd.batch import BatchSolver
+    for name in ("quad_ea_N30", "quad_quat_N30", "quad_ea_hover_N40", "quad_quat_hover_N40", "quad_quat_fullw_N30",
+                 "quad_ea_euler_N30"):
+        g = load_golden(name)
+        r = _solve(g, g["x0"], g["u_init"], flags=_lib.FLAG_LAPACK_EIGVALS)
+        n = compare_to_golden(g, r["x"], r["u"], r["J"], r["iters"], r["status"], r["ls"], r["acc"], r["regu"], J0=r["J0"],
+                              label=name + " (LAPACK's rule)")
+        assert n >= min_compared(name, g), (name, n)
+    for name in ("quad_ea_N100", "quad_quat_N80"):
+        g = load_golden(name)
+        r = _solve(g, g["x0"], g["u_init"], flags=_lib.FLAG_LAPACK_EIGVALS)
+        same = (r["status"] == g["status"]).mean()
+        print(name, "with LAPACK's rule: exits", np.bincount(r["status"], minlength=4), "reference",
+              np.bincount(g["status"], minlength=4), "same exit on %.2f" % same, "mean iterations %.1f / %.1f"
+              % (r["iters"].mean(), g["iters"].mean()))
+        assert same >= 0.6, (name, r["status"], g["status"])
+        assert abs(r["iters"].mean() - g["iters"].mean()) <= 0.3 * g["iters"].mean(), name
+    g = load_golden("quad_ea_N30")
+    B = len(g["x0"])
+    with pytest.raises(Exception, match="LAPACK_EIGVALS"):
+        BatchSolver(2, np.tile(np.asarray(g["par"], dtype=np.float64), (B, 1)), int(g["N"]), 5, 5, 1e-3,
+                    flags=_lib.FLAG_LAPACK_EIGVALS | _lib.FLAG_PARAMS_PER_TRAJECTORY).solve(g["x0"], g["u_init"])
+
+
 def test_line_search_counters_and_plant_horizon(torch_gpu):
     """iLQRController.py:57-58, :69-74: after run_ilqr, num_ls_success / num_ls_fails describe the last iteration that
     reached the line search (a call in which none did leaves them alone).  acrobot.py:139: the plant's cost_trj sums over

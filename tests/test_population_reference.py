@@ -207,3 +207,20 @@ def test_hip_against_the_reference_quadrotor_population(kind):
     d = _apart(ref, cp(r.iters), cp(r.status), cp(r.regu_rounds), "hip, " + kind)
     assert d["same_status"] >= 0.78 and d["same_iters"] >= 0.6, d
     assert d["exits"] <= 0.2 and d["iters"] <= 0.27, d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["quad_ea", "quad_quat"])
+def test_hip_with_lapacks_rule_against_the_reference_quadrotor_population(kind):
+    """ILQR_FLAG_LAPACK_EIGVALS in the 16-lanes-per-trajectory kernel: every test of the regularisation loop is LAPACK's,
+    on the reference's running sum.  The population is then the reference's to the margins the checker reaches."""
+    import torch
+    assert torch.cuda.is_available(), "this test needs a GPU"
+    from ilqr_amd import _lib
+    from ilqr_amd.batch import BatchSolver
+    ref, par, x0, u0, sp = _quad(kind)
+    r = BatchSolver(dict(quad_ea=2, quad_quat=3)[kind], par, sp["N"], sp["max_iter"], sp["max_ls"], sp["d_tol"],
+                    flags=_lib.FLAG_LAPACK_EIGVALS).solve(x0, u0)
+    cp = lambda t: t.cpu().numpy()
+    d = _apart(ref, cp(r.iters), cp(r.status), cp(r.regu_rounds), "hip, LAPACK's rule, " + kind)
+    assert d["exits"] <= 0.04 and d["iters"] <= 0.05 and d["regu"] <= 0.05, d

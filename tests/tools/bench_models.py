@@ -39,12 +39,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--kinds", default="acrobot,quad_ea,quad_quat")
 ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--cpu", type=int, default=512)
+ap.add_argument("--lapack-eigvals", action="store_true", help="ILQR_FLAG_LAPACK_EIGVALS")
 a = ap.parse_args()
 for kind in a.kinds.split(","):
     mid, par, N, mi, ml, dt = cfg(kind)
     B = a.batch
     x0, u0 = inputs(kind, np.random.default_rng(2), B, N)
-    s = BatchSolver(mid, par, N, mi, ml, dt)
+    s = BatchSolver(mid, par, N, mi, ml, dt, flags=32 if a.lapack_eigvals else 0)
     x0d = torch.as_tensor(x0).cuda().t().contiguous(); u_init = torch.as_tensor(u0).cuda().permute(1, 2, 0).contiguous()
     u = u_init.clone(); x = torch.empty((N, x0.shape[1], B), dtype=torch.float64, device="cuda"); out = s.alloc_outputs(B)
     for rep in range(2):
