@@ -485,6 +485,16 @@ __device__ __forceinline__ void build_regularised(double* L, double coef, const 
     }
 }
 
+// The reference's own accumulation (iLQRController.py:111-115): Q(r) = Q(r - 1) + 2^(r-1) P, one rounded addition per
+// round.  v += 2^k0 p, 2^(k0+1) p, ..., `count` terms (ILQR_FLAG_LAPACK_EIGVALS; the default mode forms
+// Q(0) + (2^r - 1) P with one fused multiply-add, which differs from this in the last bits).
+__device__ __forceinline__ double running_sum(double v, double p, int k0, int count)
+{
+#pragma clang fp contract(off)
+    for (int i = 0; i < count; ++i) v += ldexp(p, k0 + i);
+    return v;
+}
+
 // ------------------------------------------------------------------
 // One stage of the backward Riccati sweep: iLQRController.py:103-122 with
 // Model.Q_terms (model.py:45-53), the regularisation loop (:106-115), _gains
@@ -589,12 +599,14 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
         double mq = 0.0;
         if (g < nsrc) {
             double L[NL];
-            build_regularised<NL>(L, regu_coef(c + 1), ldsP + g * NL, park - lane + srcs[g]);
+            if constexpr (!EXACT) build_regularised<NL>(L, regu_coef(c + 1), ldsP + g * NL, park - lane + srcs[g]);
             if constexpr (EXACT) {
                 double U[NUP > 0 ? NUP : 1];
+                const double* const q0 = park - lane + srcs[g];
                 ILQR_UNROLL
-                for (int e = 0; e < NUP; ++e)
-                    U[e] = __builtin_fma(regu_coef(c + 1), ldsPU[g * NUP + e], ldsQU[g * NUP + e]);
+                for (int e = 0; e < NL; ++e) L[e] = running_sum(q0[e * 64], ldsP[g * NL + e], 0, c + 1);
+                ILQR_UNROLL
+                for (int e = 0; e < NUP; ++e) U[e] = running_sum(ldsQU[g * NUP + e], ldsPU[g * NUP + e], 0, c + 1);
                 mq = max_abs_packed<NL>(L, mq);
                 fill_full<n, m>(E, L, U);
                 t = E.has_negative();
@@ -629,12 +641,14 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
                 ILQR_UNROLL
                 for (int e = 0; e < NL; ++e) q0[e] = park[e * 64];
                 ILQR_PHASE_BARRIER();
-                ILQR_UNROLL
-                for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(coef, pe[e], q0[e]);
                 if constexpr (EXACT) {
                     ILQR_UNROLL
-                    for (int e = 0; e < NUP; ++e) QU[e] = __builtin_fma(coef, PUown[e], QU[e]);
+                    for (int e = 0; e < NL; ++e) park[e * 64] = running_sum(q0[e], pe[e], 0, r);
+                    ILQR_UNROLL
+                    for (int e = 0; e < NUP; ++e) QU[e] = running_sum(QU[e], PUown[e], 0, r);
                 } else {
+                    ILQR_UNROLL
+                    for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(coef, pe[e], q0[e]);
                     // the entries above the diagonal get the mirrored entries of P (P is symmetric up to rounding)
                     ILQR_UNROLL
                     for (int i = 0; i < n; ++i)
@@ -672,50 +686,95 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
             for (int e = 0; e < NL; ++e) ldsP[e] = PL[e];
             if constexpr (EXACT) {
                 ILQR_UNROLL
-                for (int e = 0; e < NUP; ++e) {
-                    ldsQU[e] = QU[e];
-                    ldsPU[e] = PUown[e];
-                }
+                for (int e = 0; e < NUP; ++e) ldsPU[e] = PUown[e];
             }
         }
-        for (int base = REGU_BASE + 1;; base += 64) {
-            wave_sync();     // P and Q(0) are read from LDS again on every trip, not held in registers across the loop
-            double L[NL];
-            build_regularised<NL>(L, regu_coef(base + lane), ldsP, park - lane + src);
-            double mq = 0.0;
-            int t;
-            if constexpr (EXACT) {
-                double U[NUP > 0 ? NUP : 1];
+        if constexpr (EXACT) {
+            // The running sum after `base` rounds waits in LDS (lower triangle behind P, upper entries where Q(0)'s
+            // were published); lane l adds l further rounds to it, and when none of the 64 stops the test the
+            // checkpoint moves on by 64 rounds.
+            double* const ckL = ldsP + NL;
+            double* const ckU = ldsQU;
+            double* const outU = ldsQU + (NUP > 0 ? NUP : 1);
+            if (lane == src) {
                 ILQR_UNROLL
-                for (int e = 0; e < NUP; ++e)
-                    U[e] = __builtin_fma(regu_coef(base + lane), ldsPU[e], ldsQU[e]);
-                mq = max_abs_packed<NL>(L, mq);
-                fill_full<n, m>(E, L, U);
-                t = E.has_negative();
-            } else {
-                t = has_negative_eig_packed<w, UF>(L, mq);
+                for (int e = 0; e < NL; ++e) ckL[e] = running_sum(park[e * 64], ldsP[e], 0, REGU_BASE + 1);
+                ILQR_UNROLL
+                for (int e = 0; e < NUP; ++e) ckU[e] = running_sum(QU[e], PUown[e], 0, REGU_BASE + 1);
             }
-            const unsigned long long stops = __ballot(t != 1);
-            if (stops) {
-                const int win = __ffsll((long long)stops) - 1;
-                const int tw = __shfl(t, win);
-                const double mqw = __shfl(mq, win);
+            for (int base = REGU_BASE + 1;; base += 64) {
                 wave_sync();
-                if (lane == src) {
-                    r = base + win;
-                    const double cw = regu_coef(r);
-                    double pe[NL], q0[NL];
+                double mq = 0.0;
+                {
+                    double L[NL], U[NUP > 0 ? NUP : 1];
                     ILQR_UNROLL
-                    for (int e = 0; e < NL; ++e) pe[e] = ldsP[e];
+                    for (int e = 0; e < NL; ++e) L[e] = running_sum(ckL[e], ldsP[e], base, lane);
                     ILQR_UNROLL
-                    for (int e = 0; e < NL; ++e) q0[e] = park[e * 64];
-                    ILQR_PHASE_BARRIER();
-                    ILQR_UNROLL
-                    for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(cw, pe[e], q0[e]);
-                    if constexpr (EXACT) {
+                    for (int e = 0; e < NUP; ++e) U[e] = running_sum(ckU[e], ldsPU[e], base, lane);
+                    mq = max_abs_packed<NL>(L, mq);
+                    fill_full<n, m>(E, L, U);
+                }
+                const int t = E.has_negative();
+                const unsigned long long stops = __ballot(t != 1);
+                if (stops) {
+                    const int win = __ffsll((long long)stops) - 1;
+                    const int tw = __shfl(t, win);
+                    const double mqw = __shfl(mq, win);
+                    wave_sync();
+                    if (lane == win) {      // the accepted matrix, built again (the test destroyed it), to its owner
+                        double* const dst = park - lane + src;
                         ILQR_UNROLL
-                        for (int e = 0; e < NUP; ++e) QU[e] = __builtin_fma(cw, PUown[e], QU[e]);
-                    } else {
+                        for (int e = 0; e < NL; ++e) dst[e * 64] = running_sum(ckL[e], ldsP[e], base, win);
+                        ILQR_UNROLL
+                        for (int e = 0; e < NUP; ++e) outU[e] = running_sum(ckU[e], ldsPU[e], base, win);
+                    }
+                    wave_sync();
+                    if (lane == src) {
+                        r = base + win;
+                        ILQR_UNROLL
+                        for (int e = 0; e < NUP; ++e) QU[e] = outU[e];
+                        ok = ok && (tw >= 0);
+                        maxq = fmax(maxq, mqw);
+                    }
+                    break;
+                }
+                if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
+                    if (lane == src) ok = false;
+                    break;
+                }
+                wave_sync();
+                if (lane == 63) {
+                    ILQR_UNROLL
+                    for (int e = 0; e < NL; ++e) ckL[e] = running_sum(ckL[e], ldsP[e], base, 64);
+                    ILQR_UNROLL
+                    for (int e = 0; e < NUP; ++e) ckU[e] = running_sum(ckU[e], ldsPU[e], base, 64);
+                }
+            }
+        } else {
+            for (int base = REGU_BASE + 1;; base += 64) {
+                wave_sync();     // P and Q(0) are read from LDS again on every trip, not held in registers across the loop
+                double L[NL];
+                build_regularised<NL>(L, regu_coef(base + lane), ldsP, park - lane + src);
+                double mq = 0.0;
+                int t;
+                t = has_negative_eig_packed<w, UF>(L, mq);
+                const unsigned long long stops = __ballot(t != 1);
+                if (stops) {
+                    const int win = __ffsll((long long)stops) - 1;
+                    const int tw = __shfl(t, win);
+                    const double mqw = __shfl(mq, win);
+                    wave_sync();
+                    if (lane == src) {
+                        r = base + win;
+                        const double cw = regu_coef(r);
+                        double pe[NL], q0[NL];
+                        ILQR_UNROLL
+                        for (int e = 0; e < NL; ++e) pe[e] = ldsP[e];
+                        ILQR_UNROLL
+                        for (int e = 0; e < NL; ++e) q0[e] = park[e * 64];
+                        ILQR_PHASE_BARRIER();
+                        ILQR_UNROLL
+                        for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(cw, pe[e], q0[e]);
                         ILQR_UNROLL
                         for (int i = 0; i < n; ++i)
                             ILQR_UNROLL
@@ -726,15 +785,15 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
                             ILQR_UNROLL
                             for (int j = i + 1; j < m; ++j)
                                 QU[upp(m, i, j, QP::UUB)] = __builtin_fma(cw, ldsP[tri(n + j, n + i)], QU[upp(m, i, j, QP::UUB)]);
+                        ok = ok && (tw >= 0);
+                        maxq = fmax(maxq, mqw);
                     }
-                    ok = ok && (tw >= 0);
-                    maxq = fmax(maxq, mqw);
+                    break;
                 }
-                break;
-            }
-            if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
-                if (lane == src) ok = false;
-                break;
+                if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
+                    if (lane == src) ok = false;
+                    break;
+                }
             }
         }
     }

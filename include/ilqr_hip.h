@@ -98,8 +98,11 @@ enum {
      * 1e-14 perturbation of its inputs.  They part where Q has been regularised to ~1e16 times its own size or has
      * lost its symmetry (long horizons: CarModel N = 200; the quadrotors far from hover): there LAPACK keeps calling Q
      * indefinite for tens of rounds more, and this flag reproduces the reference's exit classes and iteration
-     * counts as a population.  An eigenvalue computation per test instead of a factorisation: about 30x slower on the
-     * headline batch.  Car, acrobot and user-defined plants (one trajectory per lane); the 12-state plants refuse it. */
+     * counts as a population.  In this mode the regularised matrix is also accumulated round by round like the
+     * reference's `Q += regu * f'f` (:111-115) and P = (0.1 f)'f is formed like NumPy's matrix product.  An eigenvalue
+     * computation per test instead of a factorisation: several hundred times slower on the headline batch.  Car,
+     * acrobot, user-defined plants with ndx + nu <= 8, and the two quadrotors with one parameter block for the batch;
+     * refused (ILQR_E_BADARG) for wider user-defined plants and for quadrotors with ILQR_FLAG_PARAMS_PER_TRAJECTORY. */
     ILQR_FLAG_LAPACK_EIGVALS = 32
 };
 

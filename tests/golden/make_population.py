@@ -14,6 +14,8 @@ With plant=acrobot: the contract's second configuration (Acrobot2DModel N=100, m
 x0 ~ U(-pi,pi)^2 x U(-1,1)^2, u_init ~ N(0,1), `acrobot_inputs(n, 2)`) -> tests/golden/acrobot_population_ref.npz.
 With plant=quad_ea / quad_quat: configurations 3 and 4 (far from hover, u_init = 2 N(0,1); N = 100 / 80,
 `quad_inputs`) -> tests/golden/quad_ea_population_ref.npz / quad_quat_population_ref.npz.
+With plant=car_n200: configuration 5, the stress horizon (CarModel N = 200 from the headline workload's box of starts,
+`car_inputs(n, 5, 200)`; every such solve is ill conditioned) -> tests/golden/car_n200_population_ref.npz.
 """
 import os
 import sys
@@ -31,6 +33,7 @@ import make_golden as mg  # noqa: E402
 
 SPEC = dict(model="car", r=2.0, v_target=2.0)
 SP = dict(N=40, max_iter=50, max_ls=20, d_tol=1e-3)
+SP200 = dict(N=200, max_iter=50, max_ls=20, d_tol=1e-3)
 
 
 def acrobot_inputs(n, seed, N=100):
@@ -81,6 +84,11 @@ def main():
         x0, u0 = acrobot_inputs(n, 2)
         jobs = [(x0[b], u0[b], mg.acrobot_spec(100), ACROBOT_SP) for b in range(n)]
         name, seed = "acrobot_population_ref.npz", 2
+    elif plant == "car_n200":
+        from bench import car_inputs
+        x0, u0 = car_inputs(n, 5, SP200["N"])
+        jobs = [(x0[b], u0[b], SPEC, SP200) for b in range(n)]
+        name, seed = "car_n200_population_ref.npz", 5
     else:
         from bench import car_inputs
         x0, u0 = car_inputs(n, 1234, SP["N"])
@@ -91,7 +99,7 @@ def main():
     with ProcessPoolExecutor(workers) as pool:
         for i, r in enumerate(pool.map(one, jobs, chunksize=4)):
             out.append(r)
-            if (i + 1) % 512 == 0:
+            if (i + 1) % 32 == 0:
                 sys.stderr.write(f"{i + 1}/{n} after {time.time() - t0:.0f} s\n")
     a = np.array(out, dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, name), n=n, seed=seed,
