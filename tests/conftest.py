@@ -18,7 +18,7 @@ def pytest_configure(config):
 
 def golden_names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not p.endswith("units.npz") and not os.path.basename(p).startswith(("user_", "quat_utils", "car_population", "acrobot_population", "quad_ea_population", "quad_quat_population", "eig_decisions")))
+                  if not p.endswith("units.npz") and not os.path.basename(p).startswith(("user_", "quat_utils", "car_population", "car_n200_population", "acrobot_population", "quad_ea_population", "quad_quat_population", "eig_decisions")))
 
 
 def load_golden(name):
