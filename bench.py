@@ -181,11 +181,15 @@ def main():
     # whole batch on one stream, so that a kernel's duration is its own: in the timed region the batch is cut
     # into parts whose kernels overlap on the GPU and stretch each other.
     from ilqr_amd import _lib
-    solver.flags |= _lib.FLAG_TIMING | _lib.FLAG_SINGLE_STREAM
+    # iterations the timed solves did not run because they repeat the one before them exactly (ILQR_FLAG_NO_REPLAY in
+    # include/ilqr_hip.h); the solve below runs every iteration, so that the counts it leaves are the work its kernels did
+    replayed = int(out["replayed"].sum().item())
+    replayed_solves = int((out["replayed"] > 0).sum().item())
+    solver.flags |= _lib.FLAG_TIMING | _lib.FLAG_SINGLE_STREAM | _lib.FLAG_NO_REPLAY
     step()
     sync()
     phases = solver.last_timing()
-    solver.flags &= ~(_lib.FLAG_TIMING | _lib.FLAG_SINGLE_STREAM)
+    solver.flags &= ~(_lib.FLAG_TIMING | _lib.FLAG_SINGLE_STREAM | _lib.FLAG_NO_REPLAY)
 
     # counts of the work actually done (rank 0's shard; every shard is statistically alike)
     iters = int(out["iters"].sum().item())
@@ -229,6 +233,10 @@ def main():
             "ms_per_iter": 1e3 * elapsed / a.steps / max(iters / B, 1e-9),
             "mean_iters": iters / B, "mean_ls_evals": ls_total / B, "mean_regu_rounds": regu_rounds / B,
             "exit_counts": {"d_tol": status[0], "deltaJ<1": status[1], "max_iter": status[2], "linalg": status[3]},
+            "replay": {"solves": replayed_solves, "iterations": replayed,
+                       "note": "iterations of the timed solves that were not run because they repeat the previous one "
+                               "exactly (outputs identical bit for bit, tests/test_replay.py); the roofline solve runs "
+                               "every iteration"},
             "roofline": {"kernel": "pipe_backward_kernel<CarModel>", "bound": "mfma",
                          "bound_note": "fp64 arithmetic on the vector ALUs (7x7 per-lane matrices, no MFMA); on MI355X "
                                        "the fp64 vector peak equals the fp64 matrix peak",
@@ -238,7 +246,8 @@ def main():
                          "traffic_source": "profiles/traffic_latest.json: FETCH_SIZE and WRITE_SIZE of separate rocprofv3 --pmc "
                                            "passes over this command (tools/collect_traffic.py), not collected in this run",
                          "timing": "HIP events around each launch, one extra solve of the same batch on a single stream "
-                                   "(ILQR_FLAG_TIMING | ILQR_FLAG_SINGLE_STREAM); the timed region overlaps 3 parts",
+                                   "(ILQR_FLAG_TIMING | ILQR_FLAG_SINGLE_STREAM | ILQR_FLAG_NO_REPLAY); the timed region "
+                                   "overlaps 3 parts",
                          "launches_per_solve": bw_launches, "kernel_ms_per_solve": bw_ms,
                          "avg_launch_ms": bw_ms / max(bw_launches, 1), "algorithmic_flops_per_solve": f_bwd,
                          "line_search": {"kernels": "pipe_forward1 / pipe_backtrack_group / pipe_commit", "bound": "hbm",

@@ -21,6 +21,7 @@ FLAG_TIMING = 4
 FLAG_SINGLE_STREAM = 8
 FLAG_PARAMS_PER_TRAJECTORY = 16
 FLAG_LAPACK_EIGVALS = 32
+FLAG_NO_REPLAY = 64
 PHASES = ("init", "backward", "forward1", "backtrack", "commit", "export")
 
 EXPORTS = ("ilqr_model_info", "ilqr_workspace_bytes", "ilqr_solve_batch", "ilqr_rollout_cost",
@@ -39,7 +40,8 @@ class Problem(C.Structure):
 
 class Outputs(C.Structure):
     _fields_ = [(k, _dp) for k in ("J0", "J", "dmax", "max_abs_q", "iters", "status", "regu_rounds", "ls_total",
-                                   "regu_stages", "ls_evals", "accepted", "J_trace", "deltaJ_trace", "last_search")]
+                                   "regu_stages", "ls_evals", "accepted", "J_trace", "deltaJ_trace", "last_search",
+                                   "replayed")]
 
 
 class Timing(C.Structure):

@@ -43,6 +43,7 @@ class BatchResult:
     ls_total: torch.Tensor
     regu_stages: torch.Tensor = None
     last_search: torch.Tensor = None      # 0 no line search in this call, 1 the last one accepted, 2 it was abandoned
+    replayed: torch.Tensor = None         # iterations not run because they repeat the one before them exactly
     traces: dict = field(default_factory=dict)
 
 
@@ -134,7 +135,8 @@ class BatchSolver:
                  regu_rounds=torch.empty(stride, dtype=torch.int32, device=dev),
                  ls_total=torch.empty(stride, dtype=torch.int32, device=dev),
                  regu_stages=torch.empty(stride, dtype=torch.int32, device=dev),
-                 last_search=torch.empty(stride, dtype=torch.int32, device=dev))
+                 last_search=torch.empty(stride, dtype=torch.int32, device=dev),
+                 replayed=torch.empty(stride, dtype=torch.int32, device=dev))
         if self.trace_len:
             T = self.trace_len
             o.update(ls_evals=torch.zeros((T, stride), dtype=torch.int32, device=dev),
@@ -193,7 +195,7 @@ class BatchSolver:
                            J0=out["J0"], J=out["J"], dmax=out["dmax"], max_abs_q=out["max_abs_q"],
                            iters=out["iters"], status=out["status"], regu_rounds=out["regu_rounds"],
                            ls_total=out["ls_total"], regu_stages=out["regu_stages"], last_search=out["last_search"],
-                           traces=tr)
+                           replayed=out["replayed"], traces=tr)
 
     def rollout_cost(self, x0, u):
         """Model.rollout + cost_trj for a batch: returns (x [B, N, nx], J [B])."""

@@ -80,6 +80,8 @@ struct Pipe {
     int32_t *idA, *idB, *ls_slot, *ls_dest, *bt, *bt2;
     int32_t* ls_from;          // per line-search entry: number of the first evaluation still to be made
     int32_t* pred;             // per trajectory id: 1 if its last search rejected alpha = 1
+    int32_t* frozen;           // per trajectory id: evaluations of its last search if every further iteration repeats it (else 0)
+    int32_t* replayed;         // per trajectory id: iterations written by replay_rest instead of being run
     int32_t* win_ls;           // per line-search entry: evaluation number the search stopped at (< 0: not accepted)
     double* win_J;             // ... and that candidate's cost
     int32_t* cnt;              // [0] slots handed out in B, [1] line-search entries, [2] rejected at alpha = 1,
@@ -169,6 +171,8 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
     a.ls_total[b] = 0;
     a.last_search[b] = 0;
     a.pred[b] = 0;
+    a.frozen[b] = 0;
+    a.replayed[b] = 0;
 }
 
 // The loop test of :43 failed before the first iteration (d_tol is +inf/NaN or
@@ -206,6 +210,30 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_export_kernel(Pipe a)
     for (int i = 0; i < nx; ++i) a.x[(long)(S * nx + i) * a.cap + b] = xu[i];
 }
 
+// Iteration `it` of a frozen trajectory (see record_search) got as far as its line search, with this backward pass's
+// own counts rr, rs and expected reduction deltaJ: that search and, while the loop test of iLQRController.py:43 holds,
+// every iteration up to max_iter would repeat the previous one.  Their traces and counters are written here; J,
+// dmax, last_search and the trajectory stay as they are.  Returns the exit status.
+__device__ __forceinline__ int replay_rest(const Pipe& a, int id, int it, int ls, int rr, int rs, double deltaJ, double dmax)
+{
+    const int last = (dmax > a.d_tol) ? a.max_iter : it;       // the last iteration that runs
+    const double J = a.J[id];
+    for (int t = it; t <= last && t <= a.trace_len; ++t) {
+        const long q = (long)(t - 1) * a.cap + id;
+        if (a.tr_dJ) a.tr_dJ[q] = deltaJ;
+        if (a.tr_ls) a.tr_ls[q] = ls;
+        if (a.tr_acc) a.tr_acc[q] = 0;
+        if (a.tr_J) a.tr_J[q] = J;
+    }
+    const int more = last - it;                                  // iterations after this one
+    a.iters[id] = last;
+    a.regu_rounds[id] += more * rr;
+    a.regu_stages[id] += more * rs;
+    a.ls_total[id] += (more + 1) * ls;
+    a.replayed[id] = more;
+    return (dmax > a.d_tol) ? ILQR_EXIT_MAXITER : ILQR_EXIT_DTOL;
+}
+
 // ---------------------------------------------------------------- backward
 // EXACT: ILQR_FLAG_LAPACK_EIGVALS, every PSD test through the LAPACK path of eig_device.hpp
 template <class M, bool PT = false, bool EXACT = false>
@@ -239,6 +267,8 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
             a.status[id] = ILQR_EXIT_LINALG;
         } else if (deltaJ < 1.0) {                                                    // :50-51
             a.status[id] = ILQR_EXIT_SMALL_DELTAJ;
+        } else if (a.frozen[id] != 0) {
+            a.status[id] = replay_rest(a, id, it, a.frozen[id], rr, rs, deltaJ, dmax);
         } else {
             need_ls = true;
             a.dJ[s] = deltaJ;
@@ -269,8 +299,20 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
     if (side) a.bt[q] = j;
 }
 
+// A solve can reach a state from which every further iteration repeats the last one exactly.  When a search is
+// abandoned the trajectory is kept (iLQRController.py:69-74), so the next backward pass and every candidate of the next
+// search are the same numbers again; only J, which became the last candidate's cost (:79), is new.  If that next
+// search is abandoned as well and leaves the J it started from (the same last candidate: equal bit for bit, or NaN
+// both times), the iteration after it starts from the same x, u and J and so ends the same way, and so on until
+// max_iter.  record_search notes this (frozen = evaluations of the repeated search); the backward kernels then write
+// what the remaining iterations would leave behind (replay_rest) instead of running them.
 __device__ __forceinline__ void record_search(const Pipe& a, int id, int ls, bool complete, double Jn)
 {
+    {
+        const double Jold = a.J[id];
+        const bool again = !complete && a.last_search[id] == 2 && !(a.flags & ILQR_FLAG_NO_REPLAY);
+        a.frozen[id] = (again && (Jold == Jn || (Jold != Jold && Jn != Jn))) ? ls : 0;
+    }
     const int it = a.iters[id];
     if (it <= a.trace_len) {
         const long q = (long)(it - 1) * a.cap + id;

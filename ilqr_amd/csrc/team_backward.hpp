@@ -768,6 +768,8 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
             a.status[id] = ILQR_EXIT_LINALG;
         } else if (deltaJ < 1.0) {                                                    // :50-51
             a.status[id] = ILQR_EXIT_SMALL_DELTAJ;
+        } else if (a.frozen[id] != 0) {      // every further iteration repeats the last one (record_search)
+            a.status[id] = replay_rest(a, id, it, a.frozen[id], rr, rs, deltaJ, dmax);
         } else {
             need_ls = true;
             a.dJ[s] = deltaJ;

@@ -103,7 +103,14 @@ enum {
      * computation per test instead of a factorisation: several hundred times slower on the headline batch.  Car,
      * acrobot, user-defined plants with ndx + nu <= 8, and the two quadrotors with one parameter block for the batch;
      * refused (ILQR_E_BADARG) for wider user-defined plants and for quadrotors with ILQR_FLAG_PARAMS_PER_TRAJECTORY. */
-    ILQR_FLAG_LAPACK_EIGVALS = 32
+    ILQR_FLAG_LAPACK_EIGVALS = 32,
+    /* Run every iteration.  By default a solve that has reached a state from which every further iteration repeats the
+     * last one exactly -- two abandoned line searches in a row that leave the same J (control/iLQRController.py:69-79:
+     * the trajectory is kept, so backward pass and candidates are the same numbers again) -- is not iterated to
+     * max_iter: the counters, traces and exit status those iterations would leave are written directly.  The outputs
+     * are the same bit for bit either way (ilqr_outputs::replayed says how many iterations were written that way);
+     * the flag is for checking exactly that. */
+    ILQR_FLAG_NO_REPLAY = 64
 };
 
 /* Kernel phases of ilqr_solve_batch, for ilqr_timing. */
@@ -145,6 +152,8 @@ typedef struct {
     int32_t *last_search;/* the last line search of this call: 0 no iteration reached it, 1 it accepted a
                           * candidate, 2 it was abandoned: num_ls_success / num_ls_fails as the reference leaves
                           * them after run_ilqr (iLQRController.py:57-58, :69-74) */
+    int32_t *replayed;   /* iterations (counted in iters) that were not run because they repeat the one before them
+                          * exactly; see ILQR_FLAG_NO_REPLAY.  0 with that flag */
 } ilqr_outputs;
 
 /* model.get_dims(): control/models/model.py:9-10.  npar = doubles in the parameter block. */

@@ -49,7 +49,7 @@ def test_model_info(L):
 def test_struct_layout_matches_header():
     from ilqr_amd import _lib
     assert C.sizeof(_lib.Problem) == 64     # 4 int32, double, 2 int64, pointer, 4 int32
-    assert C.sizeof(_lib.Outputs) == 14 * 8
+    assert C.sizeof(_lib.Outputs) == 15 * 8
     assert C.sizeof(_lib.Timing) == 6 * 8 + 6 * 4 + 2 * 4
 
 
