@@ -80,7 +80,8 @@ struct Pipe {
     int32_t *idA, *idB, *ls_slot, *ls_dest, *bt, *bt2;
     int32_t* ls_from;          // per line-search entry: number of the first evaluation still to be made
     int32_t* pred;             // per trajectory id: 1 if its last search rejected alpha = 1
-    int32_t* frozen;           // per trajectory id: evaluations of its last search if every further iteration repeats it (else 0)
+    int32_t *rr_it, *rs_it;    // per trajectory id: regularisation rounds / regularised stages of its last backward pass
+    double* dj_it;             // ... and that pass's expected reduction (what replay_rest repeats)
     int32_t* replayed;         // per trajectory id: iterations written by replay_rest instead of being run
     int32_t* win_ls;           // per line-search entry: evaluation number the search stopped at (< 0: not accepted)
     double* win_J;             // ... and that candidate's cost
@@ -90,6 +91,14 @@ struct Pipe {
     int tail;                  // few trajectories left: every search is evaluated side by side from its first candidate
     int iter;                  // 1-based number of the iteration being run
 };
+
+// Entry of the slot -> trajectory tables idA / idB: the trajectory's index, or -1 - index for a slot retired after
+// it was handed out (retire_slot): its records are valid, nobody works on it any more.
+struct SlotId {
+    int id;
+    bool alive;
+};
+__device__ __forceinline__ SlotId slot_id(int raw) { return raw >= 0 ? SlotId{raw, true} : SlotId{-1 - raw, false}; }
 
 __device__ __forceinline__ int lane_rank(unsigned long long mask)
 {
@@ -171,7 +180,6 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
     a.ls_total[b] = 0;
     a.last_search[b] = 0;
     a.pred[b] = 0;
-    a.frozen[b] = 0;
     a.replayed[b] = 0;
 }
 
@@ -210,30 +218,6 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_export_kernel(Pipe a)
     for (int i = 0; i < nx; ++i) a.x[(long)(S * nx + i) * a.cap + b] = xu[i];
 }
 
-// Iteration `it` of a frozen trajectory (see record_search) got as far as its line search, with this backward pass's
-// own counts rr, rs and expected reduction deltaJ: that search and, while the loop test of iLQRController.py:43 holds,
-// every iteration up to max_iter would repeat the previous one.  Their traces and counters are written here; J,
-// dmax, last_search and the trajectory stay as they are.  Returns the exit status.
-__device__ __forceinline__ int replay_rest(const Pipe& a, int id, int it, int ls, int rr, int rs, double deltaJ, double dmax)
-{
-    const int last = (dmax > a.d_tol) ? a.max_iter : it;       // the last iteration that runs
-    const double J = a.J[id];
-    for (int t = it; t <= last && t <= a.trace_len; ++t) {
-        const long q = (long)(t - 1) * a.cap + id;
-        if (a.tr_dJ) a.tr_dJ[q] = deltaJ;
-        if (a.tr_ls) a.tr_ls[q] = ls;
-        if (a.tr_acc) a.tr_acc[q] = 0;
-        if (a.tr_J) a.tr_J[q] = J;
-    }
-    const int more = last - it;                                  // iterations after this one
-    a.iters[id] = last;
-    a.regu_rounds[id] += more * rr;
-    a.regu_stages[id] += more * rs;
-    a.ls_total[id] += (more + 1) * ls;
-    a.replayed[id] = more;
-    return (dmax > a.d_tol) ? ILQR_EXIT_MAXITER : ILQR_EXIT_DTOL;
-}
-
 // ---------------------------------------------------------------- backward
 // EXACT: ILQR_FLAG_LAPACK_EIGVALS, every PSD test through the LAPACK path of eig_device.hpp
 template <class M, bool PT = false, bool EXACT = false>
@@ -242,11 +226,13 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
     __shared__ double lds[stage_lds_doubles<M::NDX, M::NU, TermsOf<M>::type::AUX>() +
                           (EXACT ? exact_lds_doubles<M::NDX, M::NU>() : 0)];
     const int s0 = blockIdx.x * PIPE_WG + threadIdx.x;
-    const bool live = s0 < a.count;
+    bool live = s0 < a.count;
     const int s = live ? s0 : a.count - 1;      // a lane without a trajectory shadows the last one and stores nothing
     const int S = a.N - 1;
     bool need_ls = false, cont = false;
-    const int id = a.idA[s];
+    const SlotId sid = slot_id(a.idA[s]);
+    const int id = sid.id;
+    live = live && sid.alive;
     const RecIn T = slot_T<M>(a.TA, a.cap, s);
     const int it = a.iters[id] + 1;                                                  // :46
     double deltaJ = 0.0, dmax = 0.0, maxq = a.maxq[id];
@@ -267,11 +253,10 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
             a.status[id] = ILQR_EXIT_LINALG;
         } else if (deltaJ < 1.0) {                                                    // :50-51
             a.status[id] = ILQR_EXIT_SMALL_DELTAJ;
-        } else if (a.frozen[id] != 0) {
-            a.status[id] = replay_rest(a, id, it, a.frozen[id], rr, rs, deltaJ, dmax);
         } else {
             need_ls = true;
             a.dJ[s] = deltaJ;
+            a.rr_it[id] = rr; a.rs_it[id] = rs; a.dj_it[id] = deltaJ;      // for replay_rest
             // the loop test the trajectory will meet after this iteration's line search (:43)
             cont = (dmax > a.d_tol) && (it < a.max_iter);
             if (!cont) a.status[id] = (dmax > a.d_tol) ? ILQR_EXIT_MAXITER : ILQR_EXIT_DTOL;
@@ -301,18 +286,43 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
 
 // A solve can reach a state from which every further iteration repeats the last one exactly.  When a search is
 // abandoned the trajectory is kept (iLQRController.py:69-74), so the next backward pass and every candidate of the next
-// search are the same numbers again; only J, which became the last candidate's cost (:79), is new.  If that next
-// search is abandoned as well and leaves the J it started from (the same last candidate: equal bit for bit, or NaN
-// both times), the iteration after it starts from the same x, u and J and so ends the same way, and so on until
-// max_iter.  record_search notes this (frozen = evaluations of the repeated search); the backward kernels then write
-// what the remaining iterations would leave behind (replay_rest) instead of running them.
-__device__ __forceinline__ void record_search(const Pipe& a, int id, int ls, bool complete, double Jn)
+// search are the same numbers again; only J, which became the last candidate's cost (:79), is new.
+//   * Abandoned with a NaN cost: J is NaN from now on, no candidate can be accepted against it (:66), and the next
+//     search runs through the same candidates up to the same one (the first that is NaN, or number max_ls): same
+//     count, same J, for ever.
+//   * Abandoned, after an abandoned search, with the J it started from (the same last candidate, equal bit for bit):
+//     the next iteration starts from the same x, u and J and so ends the same way, and so on.
+// Either way every iteration up to max_iter (while the loop test of :43 holds) is this one over again.  They are not
+// run: replay_rest writes the counters, traces and exit status they would leave; J, dmax, last_search and the
+// trajectory stay as they are.  Outputs are the same bit for bit as with ILQR_FLAG_NO_REPLAY, which runs them.
+__device__ __forceinline__ void replay_rest(const Pipe& a, int id, int it, int ls, double J)
 {
-    {
-        const double Jold = a.J[id];
-        const bool again = !complete && a.last_search[id] == 2 && !(a.flags & ILQR_FLAG_NO_REPLAY);
-        a.frozen[id] = (again && (Jold == Jn || (Jold != Jold && Jn != Jn))) ? ls : 0;
+    const int rr = a.rr_it[id], rs = a.rs_it[id];
+    const double deltaJ = a.dj_it[id];
+    for (int t = it + 1; t <= a.max_iter && t <= a.trace_len; ++t) {
+        const long q = (long)(t - 1) * a.cap + id;
+        if (a.tr_dJ) a.tr_dJ[q] = deltaJ;
+        if (a.tr_ls) a.tr_ls[q] = ls;
+        if (a.tr_acc) a.tr_acc[q] = 0;
+        if (a.tr_J) a.tr_J[q] = J;
     }
+    const int more = a.max_iter - it;
+    a.iters[id] = a.max_iter;
+    a.regu_rounds[id] += more * rr;
+    a.regu_stages[id] += more * rs;
+    a.ls_total[id] += more * ls;
+    a.replayed[id] = more;
+    a.status[id] = ILQR_EXIT_MAXITER;      // the loop test held after this iteration (dest >= 0), so dmax > d_tol
+}
+
+// Records what a finished line search leaves (:69-79).  `dest` >= 0: the solve goes on after this iteration (the
+// slot it was given).  Returns true if it does not after all, because the rest was replayed: the caller then writes
+// the trajectory to the export buffer and retires the slot (retire_slot).
+__device__ __forceinline__ bool record_search(const Pipe& a, int id, int ls, bool complete, double Jn, int dest)
+{
+    const double Jold = a.J[id];
+    const bool fixed = !complete && dest >= 0 && !(a.flags & ILQR_FLAG_NO_REPLAY) &&
+                       ((Jn != Jn) || (a.last_search[id] == 2 && Jold == Jn));
     const int it = a.iters[id];
     if (it <= a.trace_len) {
         const long q = (long)(it - 1) * a.cap + id;
@@ -323,6 +333,17 @@ __device__ __forceinline__ void record_search(const Pipe& a, int id, int ls, boo
     a.ls_total[id] += ls;
     a.last_search[id] = complete ? 1 : 2;                                             // :69-74
     a.J[id] = Jn;                                                                     // :79
+    if (fixed) replay_rest(a, id, it, ls, Jn);
+    return fixed;
+}
+
+// A slot of the next iteration's buffer whose trajectory finished after the slot was handed out: the next backward
+// launch still covers it, as a lane that only rides along (slot_id).
+template <class M>
+__device__ __forceinline__ void retire_slot(const Pipe& a, const RecIn& T, int dest, int id)
+{
+    copy_traj<M>(T, final_dest<M>(a, id), a.N - 1);
+    a.idB[dest] = -1 - id;
 }
 
 // ---------------------------------------------------------------- forward, alpha = 1
@@ -342,7 +363,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward1_kernel(Pipe 
         const bool abandon = (Jn != Jn) || (1 >= a.max_ls);                            // :67
         if (complete || abandon) {
             if (!complete) copy_traj<M>(T, d, a.N - 1);    // search abandoned: the trajectory is kept (:69-72)
-            record_search(a, id, 1, complete, Jn);
+            if (record_search(a, id, 1, complete, Jn, dest)) retire_slot<M>(a, T, dest, id);
             a.pred[id] = 0;
         } else {
             need_bt = true;
@@ -376,7 +397,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_forward_level_kernel(
         const bool abandon = (Jn != Jn) || (ls >= a.max_ls);                           // :67
         if (complete || abandon) {
             if (!complete) copy_traj<M>(T, d, a.N - 1);
-            record_search(a, id, ls, complete, Jn);
+            if (record_search(a, id, ls, complete, Jn, dest)) retire_slot<M>(a, T, dest, id);
         } else {
             more = true;
         }
@@ -477,7 +498,7 @@ __global__ __launch_bounds__(PIPE_WG, FWD_WAVES) void pipe_commit_kernel(Pipe a,
     } else {
         copy_traj<M>(T, d, a.N - 1);
     }
-    record_search(a, id, ls, complete, a.win_J[j]);
+    if (record_search(a, id, ls, complete, a.win_J[j], dest)) retire_slot<M>(a, T, dest, id);
     a.pred[id] = (complete && ls == 1) ? 0 : 1;
 }
 

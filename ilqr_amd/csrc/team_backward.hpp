@@ -520,10 +520,11 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
     double* const L = lds_all + team * TEAM_ALL;
     double* const EX = L + TEAM_LDS;          // the plant's own per-team scratch
     const int s0 = blockIdx.x * (PIPE_WG / TEAM_LANES) + team;
-    const bool live = s0 < a.count;
-    const int s = live ? s0 : a.count - 1;      // a team without a trajectory shadows the last one
+    const int s = s0 < a.count ? s0 : a.count - 1;      // a team without a trajectory shadows the last one
     const int S = a.N - 1;
-    const int id = a.idA[s];
+    const SlotId sid = slot_id(a.idA[s]);
+    const int id = sid.id;
+    const bool live = s0 < a.count && sid.alive;         // (a retired slot's team only rides along)
     // a small parameter block (user plants) is copied into registers, one per trajectory if the caller gave one per
     // trajectory; a large one (weights and references) stays in memory, shared or per trajectory (PT)
     const ParCache<M> par_regs = params_of<M, PT>(a, id);
@@ -768,11 +769,10 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
             a.status[id] = ILQR_EXIT_LINALG;
         } else if (deltaJ < 1.0) {                                                    // :50-51
             a.status[id] = ILQR_EXIT_SMALL_DELTAJ;
-        } else if (a.frozen[id] != 0) {      // every further iteration repeats the last one (record_search)
-            a.status[id] = replay_rest(a, id, it, a.frozen[id], rr, rs, deltaJ, dmax);
         } else {
             need_ls = true;
             a.dJ[s] = deltaJ;
+            a.rr_it[id] = rr; a.rs_it[id] = rs; a.dj_it[id] = deltaJ;      // for replay_rest
             cont = (dmax > a.d_tol) && (it < a.max_iter);
             if (!cont) a.status[id] = (dmax > a.d_tol) ? ILQR_EXIT_MAXITER : ILQR_EXIT_DTOL;
         }

@@ -105,11 +105,12 @@ enum {
      * refused (ILQR_E_BADARG) for wider user-defined plants and for quadrotors with ILQR_FLAG_PARAMS_PER_TRAJECTORY. */
     ILQR_FLAG_LAPACK_EIGVALS = 32,
     /* Run every iteration.  By default a solve that has reached a state from which every further iteration repeats the
-     * last one exactly -- two abandoned line searches in a row that leave the same J (control/iLQRController.py:69-79:
-     * the trajectory is kept, so backward pass and candidates are the same numbers again) -- is not iterated to
-     * max_iter: the counters, traces and exit status those iterations would leave are written directly.  The outputs
-     * are the same bit for bit either way (ilqr_outputs::replayed says how many iterations were written that way);
-     * the flag is for checking exactly that. */
+     * last one exactly is not iterated to max_iter: the counters, traces and exit status those iterations would leave
+     * are written directly.  That state is an abandoned line search (control/iLQRController.py:69-79: the trajectory
+     * is kept, so the next backward pass and the next search's candidates are the same numbers) that leaves J = NaN,
+     * or that follows an abandoned search and leaves the J it started from.  The outputs are the same bit for bit
+     * either way (ilqr_outputs::replayed says how many iterations were written that way); the flag is for checking
+     * exactly that. */
     ILQR_FLAG_NO_REPLAY = 64
 };
 

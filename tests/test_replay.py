@@ -1,8 +1,9 @@
-"""Solves that reach a state from which every iteration repeats the last one exactly are not iterated to max_iter:
-after two abandoned line searches in a row that leave the same J (control/iLQRController.py:69-79: the trajectory is
-kept, so the next backward pass and the next search's candidates are the same numbers) the kernels write what the
-remaining iterations would leave behind.  Every output must equal, bit for bit, what ILQR_FLAG_NO_REPLAY gives by
-running those iterations; the reference's own records show the pattern this rests on."""
+"""Solves that reach a state from which every iteration repeats the last one exactly are not iterated to max_iter.
+An abandoned line search keeps the trajectory (control/iLQRController.py:69-79), so the next backward pass and the next
+search's candidates are the same numbers; if the search left J = NaN, or followed an abandoned search and left the J
+it started from, every later iteration is this one again, and the kernels write what those iterations would leave
+behind.  Every output must equal, bit for bit, what ILQR_FLAG_NO_REPLAY gives by running them; the reference's own
+records show the pattern this rests on."""
 import numpy as np
 import pytest
 
