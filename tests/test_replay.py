@@ -55,7 +55,9 @@ def _all_outputs(kind, cfg, x0, u0, flags, trace):
 @pytest.mark.parametrize("kind,B,flags,trace", [("car", 16384, 0, 50), ("car", 4096, 2, 0), ("car", 4096, 1, 7),
                                                 ("car", 2048, 32, 50),
                                                 ("acrobot", 2048, 0, 20), ("quad_ea", 256, 0, 20),
-                                                ("quad_quat", 256, 0, 20)])
+                                                ("quad_quat", 256, 0, 20),
+                                                # batches that run as several parts on internal streams
+                                                ("acrobot", 98304, 0, 0), ("quad_ea", 32768, 0, 3)])
 def test_replayed_iterations_leave_what_running_them_leaves(torch_gpu, oracle, kind, B, flags, trace):
     from ilqr_amd import _lib
     rng = np.random.default_rng(dict(car=1234, acrobot=2, quad_ea=3, quad_quat=4)[kind])
