@@ -54,7 +54,8 @@ def _all_outputs(kind, cfg, x0, u0, flags, trace):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,B,flags,trace", [("car", 16384, 0, 50), ("car", 4096, 2, 0), ("car", 4096, 1, 7),
                                                 ("car", 2048, 32, 50),
-                                                ("acrobot", 2048, 0, 20), ("quad_ea", 256, 0, 20),
+                                                ("acrobot", 2048, 0, 20), ("acrobot", 1024, 2, 5),
+                                                ("acrobot", 1024, 1, 0), ("quad_ea", 256, 0, 20),
                                                 ("quad_quat", 256, 0, 20),
                                                 # batches that run as several parts on internal streams
                                                 ("acrobot", 98304, 0, 0), ("quad_ea", 32768, 0, 3)])
@@ -74,4 +75,6 @@ def test_replayed_iterations_leave_what_running_them_leaves(torch_gpu, oracle, k
     # iterations as far as the outputs say
     cut = replayed > 0
     print(f"{kind}: {int(cut.sum())} of {B} solves replayed, {int(replayed.sum())} of {int(fast['iters'].sum())} iterations")
+    if kind != "car" or flags & 32:
+        assert cut.any(), "no solve of this batch was replayed: the test compares nothing"
     assert (fast["iters"][cut] == c["max_iter"]).all() and (fast["status"][cut] == 2).all() and (fast["last"][cut] == 2).all()
