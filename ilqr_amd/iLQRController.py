@@ -16,6 +16,11 @@ updated) u.  NumPy in, NumPy out; torch CUDA tensors in, torch tensors out.
 Per-trajectory diagnostics of the last call are in `self.info`
 (BatchResult: J0, J, iters, status, ls_total, regu_rounds, dmax, max_abs_q).
 
+`eigvals="lapack"` (keyword, default "ldl") makes every `np.linalg.eigvals(Q) < 0` test of the regularisation loop
+(iLQRController.py:110) LAPACK's own, operation for operation (ILQR_FLAG_LAPACK_EIGVALS): ill-conditioned solves
+then regularise, iterate and exit like the reference's; solves the reference reproduces itself are the same under
+either rule, and the default is far faster.
+
 All arithmetic runs in the HIP kernels behind libilqr_hip.so; there is no host
 implementation of the solver in this package.
 """
@@ -47,6 +52,9 @@ class iLQR:
         self.info: BatchResult | None = None
         self.device = kwargs.get("device", "cuda:0")
         self.trace_len = int(kwargs.get("trace_len", 0))
+        self.eigvals = str(kwargs.get("eigvals", "ldl"))
+        if self.eigvals not in ("ldl", "lapack"):
+            raise ValueError('eigvals must be "ldl" or "lapack"')
         self._solver = None
         self._solver_key = None
         if getattr(model, "_model_id", None) is None:
@@ -74,10 +82,12 @@ class iLQR:
     def _get_solver(self) -> BatchSolver:
         par = np.ascontiguousarray(self.model._param_block(), dtype=np.float64)
         cost_N = self._cost_N()
-        key = (par.tobytes(), self.N, self.max_iter, self.max_linesearch_iters, float(self.d_tol), self.trace_len, cost_N)
+        flags = _lib.FLAG_LAPACK_EIGVALS if self.eigvals == "lapack" else 0
+        key = (par.tobytes(), self.N, self.max_iter, self.max_linesearch_iters, float(self.d_tol), self.trace_len, cost_N,
+               flags)
         if self._solver is None or key != self._solver_key:
             self._solver = BatchSolver(self.model._model_id, par, self.N, self.max_iter, self.max_linesearch_iters,
-                                       self.d_tol, device=self.device, trace_len=self.trace_len,
+                                       self.d_tol, device=self.device, trace_len=self.trace_len, flags=flags,
                                        library=getattr(self.model, "_library", None), cost_N=cost_N)
             self._solver_key = key
         return self._solver

@@ -690,3 +690,25 @@ def test_line_search_counters_and_plant_horizon(torch_gpu):
     assert np.isclose(J, want, rtol=1e-12)
     with pytest.raises(IndexError):      # the reference indexes past the trajectory
         iLQR(Acrobot2DModel(ac.Q, ac.Qf, ac.R, 0.05, 50), N=40, max_iter=2).run_ilqr(h["x0"][0], h["u_init"][0].copy())
+
+
+def test_drop_in_class_with_lapacks_eigenvalue_rule(torch_gpu):
+    """iLQR(..., eigvals="lapack"): the regularisation loop's test (iLQRController.py:110) decided the way NumPy
+    decides it.  On the 256 headline solves the reference recorded (car_box256.npz) the exits then are the reference's
+    to one solve (15 run to max_iter, none ends in a LinAlgError; the default rule lets four of those stop early and
+    raises two LinAlgErrors), and under either rule nine solves in ten take the reference's iteration count, exit and
+    number of regularisation rounds -- the rest are solves the reference does not reproduce under a 1e-14 perturbation
+    of its own inputs either."""
+    from ilqr_amd import CarModel, iLQR
+    g = load_golden("car_box256")
+    ref_exits = np.bincount(g["status"], minlength=4)
+    for mode, tol in (("lapack", 1), ("ldl", 4)):
+        ctl = iLQR(CarModel(2, 2), N=40, max_iter=50, max_linesearch_iters=20, eigvals=mode)
+        ctl.run_ilqr(g["x0"], g["u_init"].copy())
+        it, st = ctl.info.iters.cpu().numpy(), ctl.info.status.cpu().numpy()
+        same = (it == g["iters"]) & (st == g["status"]) & (ctl.info.regu_rounds.cpu().numpy() == g["regu_rounds"])
+        exits = np.bincount(st, minlength=4)
+        assert np.abs(exits - ref_exits).max() <= tol, (mode, exits, ref_exits)
+        assert same.sum() >= 225 and same[g["dstable"].astype(bool)].all(), (mode, int(same.sum()))
+    with pytest.raises(ValueError, match="eigvals"):
+        iLQR(CarModel(2, 2), N=40, max_iter=50, eigvals="exact")
