@@ -22,7 +22,14 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 region, kernels back to back), against the fp64 peak.  `line_search` gives the same for the memory-bound forward-pass kernels
                 against the HBM peak, `solve` for all kernels of a solve together;
   cpu_baseline: the CPU checker (oracle/, a C restatement of the reference solver) on a
-                bounded sample of the same batch, one OpenMP thread per host core.
+                bounded sample of the same batch, one OpenMP thread per host core, once per eigenvalue
+                rule: `rule` "lapack" (np.linalg.eigvals restated: what the reference computes; the
+                top-level value) and, under "ldl", the checker running the kernels' default LDL' rule
+                (the like-for-like partner of the headline `value`);
+  faithful:     the same batch solved once more with ILQR_FLAG_LAPACK_EIGVALS (every test of the
+                regularisation loop is LAPACK's, as in control/iLQRController.py:110), timed after
+                the headline region: throughput, exits, iterations, and how far the population is
+                from the imported reference's own (tests/golden/car_population_ref.npz).
 """
 from __future__ import annotations
 
@@ -88,6 +95,74 @@ def streamed_bytes(nx, n, m, N, B, iters, ls_total, ls_searches):
     return float(algorithmic_bytes(nx, m, N, B) + backward + forward), float(backward), float(forward)
 
 
+def library_fingerprint():
+    """sha256 over the kernel sources the solver library is built from: what profiles/traffic_latest.json must have
+    been collected on to be reported as this run's traffic."""
+    import hashlib
+    from ilqr_amd import build as recipe
+    h = hashlib.sha256()
+    for f in sorted(recipe.sources()):
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def exit_fractions(status_counts):
+    tot = float(sum(status_counts)) or 1.0
+    return {"d_tol": status_counts[0] / tot, "deltaJ<1": status_counts[1] / tot, "max_iter": status_counts[2] / tot,
+            "linalg": status_counts[3] / tot}
+
+
+def faithful_record(dev, solver_args, x0, u_init, N, steps):
+    """The headline batch under the reference's own eigenvalue rule (ILQR_FLAG_LAPACK_EIGVALS), after the headline
+    region.  Also solves the 8192 starts of the reference population fixture and compares one by one."""
+    from ilqr_amd import _lib
+    from ilqr_amd.batch import BatchSolver
+    B = x0.shape[-1]
+    solver = BatchSolver(*solver_args, device=dev, flags=_lib.FLAG_LAPACK_EIGVALS)
+    out = solver.alloc_outputs(B)
+    u = torch.empty_like(u_init)
+    x = torch.empty((N, 5, B), dtype=torch.float64, device=dev)
+    # population fixture first: it also loads the kernels of this mode before anything is timed
+    rec = {}
+    gpath = os.path.join(ROOT, "tests", "golden", "car_population_ref.npz")
+    if N == 40 and os.path.exists(gpath):
+        g = np.load(gpath)
+        n = int(g["n"])
+        px0, pu0 = car_inputs(n, 1234)
+        r = solver.solve(px0, pu0)
+        torch.cuda.synchronize(dev)
+        it, st, rr = (t.cpu().numpy() for t in (r.iters, r.status, r.regu_rounds))
+        same = (it == g["iters"]) & (st == g["status"]) & (rr == g["regu_rounds"])
+        calm = g["max_abs_q"] < 1e5
+        ref_counts = np.bincount(g["status"], minlength=4).tolist()
+        rec["reference_population"] = {
+            "fixture": "tests/golden/car_population_ref.npz: the imported reference iLQR on %d starts of this workload" % n,
+            "ends_like_the_reference": float(same.mean()),
+            "ends_like_the_reference_max_abs_q_below_1e5": float(same[calm].mean()), "solves_below_1e5": int(calm.sum()),
+            "exit_counts": dict(zip(("d_tol", "deltaJ<1", "max_iter", "linalg"), np.bincount(st, minlength=4).tolist())),
+            "reference_exit_counts": dict(zip(("d_tol", "deltaJ<1", "max_iter", "linalg"), ref_counts)),
+            "mean_iters": float(it.mean()), "reference_mean_iters": float(g["iters"].mean()),
+            "note": "ends like the reference = same iteration count, exit reason and number of regularisation rounds"}
+        rec["reference_exit_fractions"] = exit_fractions(ref_counts)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        u.copy_(u_init)
+        solver.solve_soa(x0, u, x, out)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    status = torch.bincount(out["status"], minlength=4).cpu().tolist()
+    rec.update({"flag": "ILQR_FLAG_LAPACK_EIGVALS", "batch": B, "steps": steps, "value": B / dt, "unit": "solves/s",
+                "ms_per_step": 1e3 * dt, "mean_iters": float(out["iters"].double().mean().item()),
+                "mean_regu_rounds": float(out["regu_rounds"].double().mean().item()),
+                "mean_ls_evals": float(out["ls_total"].double().mean().item()),
+                "exit_counts": dict(zip(("d_tol", "deltaJ<1", "max_iter", "linalg"), status)),
+                "exit_fractions": exit_fractions(status),
+                "replayed_iterations": int(out["replayed"].sum().item())})
+    return rec
+
+
 GATHERED = ("J", "iters", "status")      # what the ranks exchange at the end of a step: 16 bytes per trajectory
 
 
@@ -118,6 +193,9 @@ def main():
     ap.add_argument("--lapack-eigvals", action="store_true",
                     help="ILQR_FLAG_LAPACK_EIGVALS: every PSD test the way NumPy makes it (not the headline line)")
     ap.add_argument("--check", type=int, default=2048, help="trajectories checked against the CPU checker (0 = skip)")
+    ap.add_argument("--faithful-batch", type=int, default=-1,
+                    help="trajectories of the same batch solved again under ILQR_FLAG_LAPACK_EIGVALS for the `faithful` "
+                         "record (-1 = the whole batch, 0 = skip; rank 0 of a 1-GPU run only)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -215,11 +293,20 @@ def main():
         ls_gbs = b_fwd / (ls_ms * 1e-3) / 1e9
         # HBM bytes from the hardware counters cannot be read from inside the run: they come from the last
         # rocprofv3 --pmc passes over this same command (tools/collect_traffic.py), kept in profiles/
-        traffic = None
+        traffic, traffic_note = None, "no profiles/traffic_latest.json for this workload"
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath) and B == 1 << 20 and N == 40 and not a.lapack_eigvals:
             try:
                 traffic = json.load(open(tpath))
+                # counters collected on other kernel sources than the ones this library is built from say nothing
+                # about this run: refused
+                fp = library_fingerprint()
+                if traffic.get("library_fingerprint") != fp:
+                    traffic_note = (f"profiles/traffic_latest.json was collected on library sources "
+                                    f"{traffic.get('library_fingerprint')}, this run is {fp}: not reported")
+                    traffic = None
+                else:
+                    traffic_note = "library sources match (" + fp + ")"
             except Exception:
                 traffic = None
         value = world * B * a.steps / elapsed
@@ -237,14 +324,15 @@ def main():
                        "note": "iterations of the timed solves that were not run because they repeat the previous one "
                                "exactly (outputs identical bit for bit, tests/test_replay.py); the roofline solve runs "
                                "every iteration"},
-            "roofline": {"kernel": "pipe_backward_kernel<CarModel>", "bound": "mfma",
-                         "bound_note": "fp64 arithmetic on the vector ALUs (7x7 per-lane matrices, no MFMA); on MI355X "
-                                       "the fp64 vector peak equals the fp64 matrix peak",
+            "roofline": {"kernel": "pipe_backward_kernel<CarModel>", "bound": "valu_fp64",
+                         "bound_note": "fp64 arithmetic on the vector ALUs (7x7 per-lane matrices, no MFMA instruction "
+                                       "in the kernel); 78.6 TFLOP/s is the fp64 vector peak",
                          "achieved": bw_tfl, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": bw_tfl / FP64_PEAK_TFLOPS,
                          "traffic": (traffic or {}).get("backward_hbm_bytes_per_solve"),
                          "traffic_source": "profiles/traffic_latest.json: FETCH_SIZE and WRITE_SIZE of separate rocprofv3 --pmc "
-                                           "passes over this command (tools/collect_traffic.py), not collected in this run",
+                                           "passes over this command (tools/collect_traffic.py), not collected in this run; "
+                                           + traffic_note,
                          "timing": "HIP events around each launch, one extra solve of the same batch on a single stream "
                                    "(ILQR_FLAG_TIMING | ILQR_FLAG_SINGLE_STREAM | ILQR_FLAG_NO_REPLAY); the timed region "
                                    "overlaps 3 parts",
@@ -317,11 +405,25 @@ def main():
             if a.cpu_sample and world == 1:
                 c = min(a.cpu_sample, B)
                 t1 = time.perf_counter()
-                co.solve_batch("car", par, N, 50, 20, 1e-3, x0_np[:c], u0_np[:c], nthreads=cores)
+                co.solve_batch("car", par, N, 50, 20, 1e-3, x0_np[:c], u0_np[:c], nthreads=cores, rule="lapack")
                 dt = time.perf_counter() - t1
+                t1 = time.perf_counter()
+                co.solve_batch("car", par, N, 50, 20, 1e-3, x0_np[:c], u0_np[:c], nthreads=cores, rule="ldl")
+                dt2 = time.perf_counter() - t1
                 res["cpu_baseline"] = {"value": c / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+                                       "rule": "lapack",
+                                       "rule_note": "np.linalg.eigvals restated (DGEEV): the reference's own test, the "
+                                                    "partner of the `faithful` record; the headline `value` runs the "
+                                                    "kernels' default LDL' test, whose CPU partner is `ldl`",
                                        "sample": f"first {c} trajectories of the same batch, C restatement of the "
-                                                 f"reference solver (oracle/), OpenMP over {cores} threads, {dt:.1f} s"}
+                                                 f"reference solver (oracle/), OpenMP over {cores} threads, {dt:.1f} s",
+                                       "ldl": {"value": c / dt2, "unit": "solves/s", "rule": "ldl",
+                                               "sample": f"the same {c} trajectories with the kernels' LDL' rule, {dt2:.1f} s"}}
+        if world == 1 and a.faithful_batch != 0 and not a.lapack_eigvals:
+            fb = B if a.faithful_batch < 0 else min(a.faithful_batch, B)
+            res["faithful"] = faithful_record(dev, (0, [2.0, 2.0], N, 50, 20, 1e-3), x0[:, :fb].contiguous(),
+                                              u_init[:, :, :fb].contiguous(), N, 1)
+            res["faithful"]["vs_headline"] = res["faithful"]["value"] / value
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -26,8 +26,9 @@ PHASES = ("init", "backward", "forward1", "backtrack", "commit", "export")
 
 EXPORTS = ("ilqr_model_info", "ilqr_workspace_bytes", "ilqr_solve_batch", "ilqr_rollout_cost",
            "ilqr_model_eval", "ilqr_mpc_advance", "ilqr_last_timing", "ilqr_last_error", "ilqr_version",
-           "ilqr_solve_batch_static", "ilqr_eigvals_negative", "ilqr_linearize_continuous")
+           "ilqr_solve_batch_static", "ilqr_eigvals_negative", "ilqr_linearize_continuous", "ilqr_abi_version")
 STATIC_WORKSPACE_BYTES = 32 << 20
+ABI_VERSION = 2          # ILQR_ABI_VERSION of include/ilqr_hip.h: the struct layouts declared below
 
 _dp = C.c_void_p  # device pointers travel as plain addresses
 
@@ -87,6 +88,9 @@ def lib(path=None):
     L.ilqr_last_timing.argtypes = [C.POINTER(Timing)]
     L.ilqr_last_error.restype = C.c_char_p
     L.ilqr_version.restype = C.c_char_p
+    L.ilqr_abi_version.restype = C.c_int32
+    if L.ilqr_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: struct layout version {L.ilqr_abi_version()}, this binding is written for {ABI_VERSION}")
     _libs[path] = L
     return L
 

@@ -35,6 +35,18 @@ class DeviceCallLeft(RuntimeError):
     pass
 
 
+def is_kernel_symbol(mangled: str) -> bool:
+    """The library's kernels are function templates or functions named <something>_kernel directly inside namespace
+    ilqr or the anonymous namespace of ilqr_hip.hip: _ZN4ilqr<len><name>_kernel... / _ZN<anon>...<len><name>_kernel....
+    A device helper that merely has `kernel` somewhere in its name or in a template argument does not match."""
+    m = re.match(r"_ZN(?:4ilqr|12_GLOBAL__N_1)(\d+)", mangled)
+    if not m:
+        return False
+    n = int(m.group(1))
+    name = mangled[m.end():m.end() + n]
+    return len(name) == n and name.endswith("_kernel")
+
+
 def check_everything_inlined(remarks: str, unit: str, may_be_empty: bool = False):
     """Every device function a kernel uses must have been inlined into it.  A kernel's scratch size is then what
     its own body spills; with a callee left out of line the size travels from callee to caller through assembler
@@ -46,7 +58,7 @@ def check_everything_inlined(remarks: str, unit: str, may_be_empty: bool = False
         return
     if not names:
         raise DeviceCallLeft(f"{unit}: no resource report from the compiler (is -Rpass-analysis still passed?)")
-    left = sorted({n for n in names if "kernel" not in n})
+    left = sorted({n for n in names if not is_kernel_symbol(n)})
     dyn = re.findall(r"Dynamic Stack: True", remarks)
     if left or dyn:
         raise DeviceCallLeft(f"{unit}: device functions left out of line (mark them __forceinline__): {left[:8]}"
@@ -60,16 +72,22 @@ def build_library(out_so, defines=(), include_dirs=(), hipcc=None, no_kernels_in
     out_dir = os.path.dirname(out_so)
     os.makedirs(out_dir, exist_ok=True)
     tag = f"{os.path.basename(out_so)}.{os.getpid()}"
-    objs, procs = [], []
+    objs, procs, logs = [], [], []
     common = [*HIPCC_FLAGS, *[f"-D{d}" for d in defines], *[f"-I{d}" for d in include_dirs]]
     for src, extra in UNITS:
         obj = os.path.join(out_dir, f".{tag}.{os.path.splitext(src)[0]}.o")
         objs.append(obj)
-        procs.append((src, subprocess.Popen([hipcc, *common, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", "-o",
-                                             obj, os.path.join(CSRC, src)], stderr=subprocess.PIPE, text=True)))
+        # each compiler writes its remarks to a file of its own: through pipes drained one after the other the second
+        # compiler would block on a full pipe until the first has finished
+        log = open(obj + ".log", "w+")
+        logs.append(log)
+        procs.append((src, log, subprocess.Popen([hipcc, *common, *extra, "-Rpass-analysis=kernel-resource-usage", "-c",
+                                                  "-o", obj, os.path.join(CSRC, src)], stderr=log, text=True)))
     try:
-        for src, p in procs:
-            _, err = p.communicate()
+        for src, log, p in procs:
+            p.wait()
+            log.seek(0)
+            err = log.read()
             rest = "\n".join(line for line in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in line
                              and not re.match(r"^\s*(\d+ \||\||\^)|^In file included from", line))
             if rest.strip():
@@ -81,7 +99,13 @@ def build_library(out_so, defines=(), include_dirs=(), hipcc=None, no_kernels_in
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp, *objs])
         os.replace(tmp, out_so)
     finally:
+        for _, _, p in procs:
+            if p.poll() is None:
+                p.kill()
+        for log in logs:
+            log.close()
         for o in objs:
-            if os.path.exists(o):
-                os.remove(o)
+            for f in (o, o + ".log"):
+                if os.path.exists(f):
+                    os.remove(f)
     return out_so

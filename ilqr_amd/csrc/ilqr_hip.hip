@@ -193,6 +193,7 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
     if (!p->params) return fail(ILQR_E_BADARG, "params is NULL");
     if (p->max_iter < 0 || p->max_ls < 0 || p->trace_len < 0) return fail(ILQR_E_BADARG, "negative count");
     if (p->cost_N < 0 || p->cost_N > p->N) return fail(ILQR_E_BADARG, "cost_N must be 0 (= N) or within 1..N");
+    if (p->reserved_ != 0) return fail(ILQR_E_BADARG, "ilqr_problem.reserved_ must be 0 (a caller built against another header?)");
     if ((p->flags & ILQR_FLAG_LAPACK_EIGVALS) && d.ndx + d.nu > 8) {
         const bool quad = p->model_id == ILQR_MODEL_QUAD_EA || p->model_id == ILQR_MODEL_QUAD_QUAT;
         if (!quad || (p->flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY))
@@ -425,7 +426,8 @@ int dispatch(int model_id, F&& f)
 extern "C" {
 
 const char* ilqr_last_error(void) { return g_err; }
-const char* ilqr_version(void) { return "ilqr_hip 0.3 (gfx950)"; }
+const char* ilqr_version(void) { return "ilqr_hip 0.4 (gfx950)"; }
+int32_t ilqr_abi_version(void) { return ILQR_ABI_VERSION; }
 
 int ilqr_last_timing(ilqr_timing* out)
 {
@@ -479,6 +481,12 @@ int ilqr_solve_batch_static(const ilqr_problem* p, const double* x0, double* u, 
     if (!x0 || !u || !x) return fail(ILQR_E_BADARG, "x0, u and x must be non-NULL");
     if (p->stride > 0x7fffffffL) return fail(ILQR_E_BADARG, "stride must fit in 31 bits");
     if (p->flags & ILQR_FLAG_TIMING) return fail(ILQR_E_BADARG, "ILQR_FLAG_TIMING creates events: not available here");
+    {   // the solve reads counters back and waits for the stream once per iteration: illegal on a capturing stream
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(ILQR_E_BADARG, "the stream is being captured into a graph: the solve blocks the host once per "
+                                       "iteration and cannot be captured");
+    }
     const WsLayout w = ws_layout(p, d);
     if (w.total > (size_t)ILQR_STATIC_WORKSPACE_BYTES) {
         char need[64];

@@ -29,7 +29,6 @@ extern "C" {
  *   QUAD_QUAT  [dt, Q(12x12), Qf(12x12), R(4x4), xref(13), uref(4), euler]   control/models/Quadrotor_Quat.py:39-59,116-126,150-153,178-180
  *   Q, Qf, R: any matrices, row-major (the reference never asks for symmetry).  euler: 0 = the RK4 step
  *   (integration="RK4"), anything else = one explicit Euler step x + xdot dt (any other `integration`).
- *              (diagonal weights only)
  * matrices are row-major. */
 enum { ILQR_MODEL_CAR = 0, ILQR_MODEL_ACROBOT = 1, ILQR_MODEL_QUAD_EA = 2, ILQR_MODEL_QUAD_QUAT = 3,
        /* a plant the user wrote (the README.md:25-31 workflow of the reference): present only in a library that
@@ -68,8 +67,16 @@ typedef struct {
                              quadrotor plants sum over the horizon they were constructed with, whatever horizon the
                              solver runs (acrobot.py:139, Quadrotor_EA.py:199, Quadrotor_Quat.py:212);
                              1 <= cost_N <= N (the reference raises IndexError beyond) */
-    int32_t reserved_;    /* 0 */
+    int32_t reserved_;    /* must be 0 (refused otherwise, so that it can be given a meaning later) */
 } ilqr_problem;
+
+/* Layout version of ilqr_problem / ilqr_outputs / ilqr_timing as this header declares them.  The structs carry no
+ * size field: a binding built against another header would hand over shorter or longer structs, so it should
+ * compare ilqr_abi_version() with the ILQR_ABI_VERSION it was written for when it loads the library.
+ *   1: ilqr_problem 56 bytes, ilqr_outputs 13 pointers      2: ilqr_problem 64 bytes (cost_N, reserved_),
+ *   ilqr_outputs 15 pointers (last_search, replayed) */
+#define ILQR_ABI_VERSION 2
+int32_t ilqr_abi_version(void);
 
 /* Line-search evaluation schedule (the result does not depend on it, bit for bit):
  * default: candidate 1 (alpha = 1) computed and written for every trajectory, except those whose previous search
@@ -178,11 +185,14 @@ size_t ilqr_workspace_bytes(const ilqr_problem *p);
 int ilqr_solve_batch(const ilqr_problem *p, const double *x0, double *u, double *x, const ilqr_outputs *out,
                      void *workspace, size_t workspace_bytes, void *stream);
 
-/* No counterpart in the reference.  ilqr_solve_batch for callers that cannot allocate device memory (code under
- * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same solve with the workspace in
+/* No counterpart in the reference.  ilqr_solve_batch for callers that cannot allocate device memory (tight serving
+ * loops, harnesses that forbid hipMalloc): the same solve with the workspace in
  * a device array that is part of the library, ILQR_STATIC_WORKSPACE_BYTES per GPU, held from the first call on
  * that GPU until the process ends.  The call allocates nothing: no hipMalloc / hipFree, no streams, events or
- * host threads (it runs on `stream` alone, as with ILQR_FLAG_SINGLE_STREAM; ILQR_FLAG_TIMING is refused).  A
+ * host threads (it runs on `stream` alone, as with ILQR_FLAG_SINGLE_STREAM; ILQR_FLAG_TIMING is refused).  Like
+ * ilqr_solve_batch it blocks the host once per solver iteration (a few bytes are read back to size the next
+ * launches), so it cannot run on a stream that is being captured into a HIP graph: such a stream is refused
+ * with ILQR_E_BADARG before anything is enqueued.  A
  * problem whose ilqr_workspace_bytes() exceeds ILQR_STATIC_WORKSPACE_BYTES is refused with ILQR_E_WORKSPACE
  * (CarModel N = 40: up to about 2 900 trajectories per call).  Results are those of ilqr_solve_batch, bit for bit.
  * All calls on one GPU share the one array: calls that overlap on the same GPU (two host threads, two streams)

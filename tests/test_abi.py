@@ -67,12 +67,14 @@ def test_argument_validation_and_workspace(L):
     assert L.ilqr_workspace_bytes(C.byref(p)) >= need
     assert L.ilqr_workspace_bytes(C.byref(prob(N=1))) == 0
     for bad in (prob(N=1), prob(B=0), prob(stride=8), prob(model_id=7), prob(params=None), prob(cost_N=41),
-                prob(cost_N=-1)):
+                prob(cost_N=-1), prob(reserved_=7)):
         assert L.ilqr_solve_batch(C.byref(bad), fake, fake, fake, None, fake, 1 << 40, None) == -1
     assert L.ilqr_solve_batch(C.byref(p), None, fake, fake, None, fake, 1 << 40, None) == -1
     assert L.ilqr_solve_batch(C.byref(p), fake, fake, fake, None, fake, 16, None) == -2
     assert L.ilqr_solve_batch(C.byref(p), fake, fake, fake, None, None, 0, None) == -2
     assert L.ilqr_version().startswith(b"ilqr_hip")
+    m = re.search(r"#define ILQR_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    assert m and L.ilqr_abi_version() == int(m.group(1)) == _lib.ABI_VERSION
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

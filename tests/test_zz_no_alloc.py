@@ -67,3 +67,48 @@ def test_static_workspace_refuses_what_does_not_fit():
     pr = s._problem(64, 64)
     pr.flags |= _lib.FLAG_TIMING
     assert s.lib.ilqr_solve_batch_static(C.byref(pr), _ptr(x0), _ptr(u), _ptr(x), None, s._stream()) == -1
+
+
+def test_static_workspace_call_leaves_device_memory_as_it_found_it():
+    """What the entry point exists for: after a first call (which loads the kernels and takes the address of the
+    library's array) a second call changes the free device memory by nothing; a capturing stream is refused."""
+    import torch
+    assert torch.cuda.is_available(), "this test needs a GPU"
+    import bench
+    from ilqr_amd import _lib
+    from ilqr_amd.batch import BatchSolver, _ptr
+    for d in range(min(torch.cuda.device_count(), 2)):       # the array's address is taken per device
+        dev = torch.device("cuda", d)
+        with torch.cuda.device(dev):
+            s = BatchSolver(0, [2.0, 2.0], 40, 50, 20, 1e-3, device=dev)
+            B = 1024
+            x0, u0 = bench.car_inputs(B, 5)
+            x0s = torch.as_tensor(x0, device=dev).t().contiguous()
+            us = torch.as_tensor(u0, device=dev).permute(1, 2, 0).contiguous()
+            x = torch.empty((40, 5, B), dtype=torch.float64, device=dev)
+            out = s.alloc_outputs(B)
+            oo = _lib.Outputs(*[_ptr(out.get(k)) for k, _ in _lib.Outputs._fields_])
+            pr = s._problem(B, B)
+            u = us.clone()
+            u2 = us.clone()
+            s._check(s.lib.ilqr_solve_batch_static(C.byref(pr), _ptr(x0s), _ptr(u), _ptr(x), C.byref(oo), s._stream()))
+            torch.cuda.synchronize(dev)
+            free0, _ = torch.cuda.mem_get_info(dev)
+            s._check(s.lib.ilqr_solve_batch_static(C.byref(pr), _ptr(x0s), _ptr(u2), _ptr(x), C.byref(oo), s._stream()))
+            torch.cuda.synchronize(dev)
+            free1, _ = torch.cuda.mem_get_info(dev)
+            assert free1 == free0, (d, free0, free1)
+            assert torch.equal(u, u2)
+            # under stream capture the call is refused before it enqueues anything
+            side = torch.cuda.Stream(device=dev)
+            g = torch.cuda.CUDAGraph()
+            u3 = us.clone()
+            with torch.cuda.stream(side):
+                g.capture_begin()
+                try:
+                    rc = s.lib.ilqr_solve_batch_static(C.byref(pr), _ptr(x0s), _ptr(u3), _ptr(x), C.byref(oo),
+                                                       C.c_void_p(side.cuda_stream))
+                    msg = s.lib.ilqr_last_error()
+                finally:
+                    g.capture_end()
+            assert rc == -1 and b"captured" in msg, (rc, msg)

@@ -15,7 +15,10 @@ import csv
 import glob
 import json
 import re
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(path, counter):
@@ -43,6 +46,7 @@ def main():
     out = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB",
         "solves_in_profile": solves,
+        "library_fingerprint": __import__("bench").library_fingerprint(),
         "per_kernel_hbm_bytes_per_solve": b,
         "per_kernel_fetch_kib_raw": dict(fetch), "per_kernel_write_kib_raw": dict(write),
         "backward_hbm_bytes_per_solve": b.get("backward", 0.0),

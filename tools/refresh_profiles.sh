@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 out=$R/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0"
+B="python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --faithful-batch 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- $B > $out/kt.log 2>&1
 ILQR_HIP_PARTS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt1 -- $B > $out/kt1.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $B > $out/fetch.log 2>&1
