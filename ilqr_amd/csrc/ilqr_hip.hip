@@ -207,7 +207,7 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
 
 struct WsLayout {
     size_t TA, TB, TOUT, G, Gscratch, dJ, J0, J, dmax, maxq, iters, status, regu_rounds, regu_stages, ls_total, last_search, idA, idB,
-        ls_slot, ls_dest, bt, bt2, ls_from, pred, rr_it, rs_it, dj_it, replayed, win_ls, win_J, cnt, total;
+        ls_slot, ls_dest, bt, bt2, ls_from, pred, rr_it, rs_it, dj_it, replayed, dirty, defer, win_ls, win_J, cnt, total;
 };
 WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
 {
@@ -226,7 +226,7 @@ WsLayout ws_layout(const ilqr_problem* p, const ModelDims& d)
     w.idA = take(cap * 4); w.idB = take(cap * 4); w.ls_slot = take(cap * 4); w.ls_dest = take(cap * 4);
     w.bt = take(cap * 4); w.bt2 = take(cap * 4);
     w.ls_from = take(cap * 4); w.pred = take(cap * 4);
-    w.rr_it = take(cap * 4); w.rs_it = take(cap * 4); w.dj_it = take(cap * 8); w.replayed = take(cap * 4);
+    w.rr_it = take(cap * 4); w.rs_it = take(cap * 4); w.dj_it = take(cap * 8); w.replayed = take(cap * 4); w.dirty = take(cap * 4); w.defer = take(cap * 4);
     w.win_ls = take(cap * 4); w.win_J = take(cap * 8);
     w.cnt = take(64 * 4 * 4);      // one block of counters per part (MAX_PARTS)
     w.total = off;
@@ -251,7 +251,7 @@ Pipe part_of(Pipe a, long lo, long n, int part)
     if (a.tr_dJ) a.tr_dJ += lo;
     a.TA += lo * Rec<M>::RT; a.TB += lo * Rec<M>::RT; a.TOUT += lo * Rec<M>::RT; a.G += lo * Rec<M>::RG; a.dJ += lo;
     a.idA += lo; a.idB += lo; a.ls_slot += lo; a.ls_dest += lo; a.bt += lo; a.bt2 += lo;
-    a.ls_from += lo; a.pred += lo; a.rr_it += lo; a.rs_it += lo; a.dj_it += lo; a.replayed += lo; a.win_ls += lo; a.win_J += lo;
+    a.ls_from += lo; a.pred += lo; a.rr_it += lo; a.rs_it += lo; a.dj_it += lo; a.replayed += lo; a.dirty += lo; a.defer += lo; a.win_ls += lo; a.win_J += lo;
     a.cnt += 64 * part;
     return a;
 }
@@ -316,6 +316,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     a.ls_from = (int32_t*)(ws + w.ls_from); a.pred = (int32_t*)(ws + w.pred);
     a.rr_it = (int32_t*)(ws + w.rr_it); a.rs_it = (int32_t*)(ws + w.rs_it); a.dj_it = (double*)(ws + w.dj_it);
     a.replayed = o.replayed ? o.replayed : (int32_t*)(ws + w.replayed);
+    a.dirty = (int32_t*)(ws + w.dirty); a.defer = (int32_t*)(ws + w.defer);
     a.win_ls = (int32_t*)(ws + w.win_ls); a.win_J = (double*)(ws + w.win_J);
     a.cnt = (int32_t*)(ws + w.cnt);
 
@@ -324,6 +325,7 @@ int run_pipeline(const ilqr_problem* p, const double* x0, double* u, double* x, 
     // keep two waves per SIMD, and thinner parts of concurrent streams were measured to land on the same SIMDs (acrobot,
     // 65 536 trajectories: 50.1 ms in three parts, 47.0 ms in two).
     const int K = parts_for(p, M::TEAM_BACKWARD ? 16384 : 32768);
+    a.parts = K;
     ilqr_timing total;
     memset(&total, 0, sizeof(total));
     if (K == 1) {

@@ -10,3 +10,16 @@ template int run_part<CarModel, false>(Pipe, hipStream_t, ilqr_timing*);
 template int run_part<UserModel, false>(Pipe, hipStream_t, ilqr_timing*);
 #endif
 }  // namespace ilqr
+
+#ifdef ILQR_DEBUG_COUNTERS
+// diagnostics build only: the counters of solver_device.hpp as this translation unit's kernels left them
+extern "C" int ilqr_debug_counters(unsigned long long* out16, int reset)
+{
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(ilqr::g_dbg), sizeof(ilqr::g_dbg)) != hipSuccess) return -3;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ilqr::g_dbg), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+#endif

@@ -106,13 +106,14 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
     // (measured on 2^20 car solves in 3 parts: 88.3 ms with 262144, 90.2 ms with 65536, 95 ms with no limit)
     long TAIL_COUNT = M::TAIL_COUNT;
     if (const char* e = getenv("ILQR_HIP_TAIL")) TAIL_COUNT = atol(e);     // for tuning
-    int32_t h[4];
-    long count = a.B;
+    int32_t h[64];
+    long count = a.B, back = 0;      // running trajectories; how many of them sit in slots handed out from the back
     int iters_run = 0;
     for (int iter = 1; iter <= a.max_iter && count > 0; ++iter) {
         iters_run = iter;
         a.count = (int)count;
         a.iter = iter;
+        a.s_first = 0; a.s_step = 1; a.group = (int)(count - back); a.lanes = PIPE_WG;
         // Latency-bound regime (about one wavefront per SIMD or less): fewer, wider launches per iteration.
         // The schedule does not change any result, so neither does the threshold.
         const bool tail = count <= TAIL_COUNT && a.max_ls >= 2 &&
@@ -133,15 +134,42 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
                                    dim3(PIPE_WG), 0, st, a);
             }
         } else if (a.flags & ILQR_FLAG_LAPACK_EIGVALS) {
-            hipLaunchKernelGGL((pipe_backward_kernel<M, PT, true>), dim3(blocks_for(count, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
+            // First the trajectories whose tests have been cheap so far, 64 per wavefront; one that turns out to need a
+            // long scan is dropped by that launch and listed.  Then those that needed one before (slots from the back)
+            // and the listed ones, spread thinly: as few per wavefront as still gives every SIMD its wavefronts (three
+            // workgroups of this kernel fit a CU), because the long scans of one wavefront's trajectories run one
+            // after the other and the launch takes as long as its slowest wavefront.  Results do not depend on it.
+            long n_defer = 0;
+            if (a.group > 0) {
+                hipLaunchKernelGGL((pipe_backward_kernel<M, PT, true, true>), dim3(blocks_for(a.group, PIPE_WG)), dim3(PIPE_WG), 0,
+                                   st, a);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(h, a.cnt + CNT_DEFER, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                n_defer = h[0];
+            }
+            if (back + n_defer > 0) {
+                Pipe b = a;
+                b.s_first = (int)a.B - 1; b.s_step = -1; b.group = (int)(back + n_defer); b.n_back = (int)back;
+                long resident = 768 / (a.parts > 0 ? a.parts : 1);
+                if (const char* e = getenv("ILQR_HIP_DIRTY_WAVES")) resident = atol(e);     // for tuning
+                long most = 16;
+                if (const char* e = getenv("ILQR_HIP_DIRTY_LANES")) most = atol(e);        // for tuning
+                int lanes = 1;
+                while (lanes < most && (long)blocks_for(b.group, 2 * lanes) >= resident) lanes *= 2;
+                b.lanes = lanes;
+                hipLaunchKernelGGL((pipe_backward_kernel<M, PT, true, false>), dim3(blocks_for(b.group, lanes)), dim3(PIPE_WG), 0,
+                                   st, b);
+            }
         } else {
             hipLaunchKernelGGL((pipe_backward_kernel<M, PT>), dim3(blocks_for(count, PIPE_WG)), dim3(PIPE_WG), 0, st, a);
         }
         tm.end();
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h, a.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h, a.cnt, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        const long next = h[0], nls = h[1];
+        const long next = h[0] + h[CNT_DIRTY], nls = h[1];
+        const long next_back = h[CNT_DIRTY];
         if (nls > 0) {
             if (!tail) {
                 tm.begin(ILQR_PHASE_FORWARD1);
@@ -215,6 +243,7 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
         double* t = a.TA; a.TA = a.TB; a.TB = t;
         int32_t* ti = a.idA; a.idA = a.idB; a.idB = ti;
         count = next;
+        back = next_back;
     }
     tm.begin(ILQR_PHASE_EXPORT);
     hipLaunchKernelGGL(pipe_export_kernel<M>, dim3(blocks_for(a.B, PIPE_WG)), dim3(PIPE_WG), 0, st, a);

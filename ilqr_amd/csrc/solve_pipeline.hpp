@@ -49,6 +49,8 @@ namespace ilqr {
 #define ILQR_FWD_WAVES 1
 #endif
 constexpr int FWD_WAVES = ILQR_FWD_WAVES;   // waves per SIMD the forward-pass kernels are built for
+constexpr int CNT_DIRTY = 62;    // index in Pipe::cnt of the number of slots handed out from the back
+constexpr int CNT_DEFER = 63;    // ... of the number of trajectories a launch left to the next one (Pipe::defer)
 constexpr int PIPE_WG = 64;      // one wavefront per workgroup: backward_stage exchanges data between lanes without barriers
 static_assert(PIPE_WG == 64, "backward_stage assumes single-wavefront workgroups");
 
@@ -83,13 +85,25 @@ struct Pipe {
     int32_t *rr_it, *rs_it;    // per trajectory id: regularisation rounds / regularised stages of its last backward pass
     double* dj_it;             // ... and that pass's expected reduction (what replay_rest repeats)
     int32_t* replayed;         // per trajectory id: iterations written by replay_rest instead of being run
+    int32_t* dirty;            // per trajectory id: 1 once a test of the trajectory needed LAPACK's path (ILQR_FLAG_LAPACK_EIGVALS)
     int32_t* win_ls;           // per line-search entry: evaluation number the search stopped at (< 0: not accepted)
     double* win_J;             // ... and that candidate's cost
     int32_t* cnt;              // [0] slots handed out in B, [1] line-search entries, [2] rejected at alpha = 1,
                                // [3..] list lengths of the later stages
     int count;                 // running trajectories = used slots of buffer A
+    // The slots one backward launch covers: s_first, s_first + s_step, ... (`group` of them), `lanes` per wavefront.
+    // Slots are handed out from both ends of the buffer: trajectories whose tests the certified screen has settled
+    // so far from the front, the others ("dirty": they run LAPACK's path at most stages) from the back, so that a
+    // wavefront holds one kind.  Wavefronts of the second kind are launched with fewer trajectories each when
+    // there are few of them: what such a launch takes is the longest chain of LAPACK tests in one wavefront.
+    int s_first, s_step, group, lanes;
+    // The launch for the second kind covers `n_back` slots counted down from s_first and then the slots listed in
+    // `defer`: trajectories that the first launch of this iteration dropped when they needed a long scan.
+    int n_back;
+    int32_t* defer;
     int tail;                  // few trajectories left: every search is evaluated side by side from its first candidate
     int iter;                  // 1-based number of the iteration being run
+    int parts;                 // parts of the batch that run concurrently (this is one of them)
 };
 
 // Entry of the slot -> trajectory tables idA / idB: the trajectory's index, or -1 - index for a slot retired after
@@ -181,6 +195,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_init_kernel(Pipe a)
     a.last_search[b] = 0;
     a.pred[b] = 0;
     a.replayed[b] = 0;
+    a.dirty[b] = 0;
 }
 
 // The loop test of :43 failed before the first iteration (d_tol is +inf/NaN or
@@ -220,14 +235,18 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_export_kernel(Pipe a)
 
 // ---------------------------------------------------------------- backward
 // EXACT: ILQR_FLAG_LAPACK_EIGVALS, every PSD test through the LAPACK path of eig_device.hpp
-template <class M, bool PT = false, bool EXACT = false>
+// DEFER: the launch for the trajectories that have not needed a long regularisation scan so far (see backward_stage)
+template <class M, bool PT = false, bool EXACT = false, bool DEFER = false>
 __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kernel(Pipe a)
 {
     __shared__ double lds[stage_lds_doubles<M::NDX, M::NU, TermsOf<M>::type::AUX>() +
                           (EXACT ? exact_lds_doubles<M::NDX, M::NU>() : 0)];
-    const int s0 = blockIdx.x * PIPE_WG + threadIdx.x;
-    bool live = s0 < a.count;
-    const int s = live ? s0 : a.count - 1;      // a lane without a trajectory shadows the last one and stores nothing
+    // (second kind: lane l of wavefront b takes entry l * wavefronts + b, so that neighbours in the list, which
+    // tend to be alike in how long their scans take, end up in different wavefronts)
+    const int i0 = (EXACT && !DEFER) ? (int)(threadIdx.x * gridDim.x + blockIdx.x) : (int)(blockIdx.x * a.lanes + threadIdx.x);
+    bool live = (int)threadIdx.x < a.lanes && i0 < a.group;
+    const int i1 = live ? i0 : a.group - 1;      // a lane without a trajectory shadows the last one and stores nothing
+    const int s = (EXACT && !DEFER && i1 >= a.n_back) ? a.defer[i1 - a.n_back] : a.s_first + a.s_step * i1;
     const int S = a.N - 1;
     bool need_ls = false, cont = false;
     const SlotId sid = slot_id(a.idA[s]);
@@ -239,8 +258,31 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
     int rr = 0, rs = 0;
     const ParCache<M> par = params_of<M, PT>(a, id);
     const RecOut G = live ? RecOut{a.G + (long)s * Rec<M>::RG, a.cap * Rec<M>::RG} : RecOut{a.Gscratch, Rec<M>::RG};
-    const bool ok = backward_pass<M, EXACT>(par.get(), T, G, S, deltaJ, dmax, rr, rs, maxq, live, lds);     // :49
+    bool dirty = EXACT ? (a.dirty[id] != 0) : false;
+    bool deferred = false;
+#ifdef ILQR_DEBUG_COUNTERS
+    const unsigned long long dbg_k0 = __builtin_readcyclecounter();
+#endif
+    const bool ok = backward_pass<M, EXACT, DEFER>(par.get(), T, G, S, deltaJ, dmax, rr, rs, maxq, live, lds, dirty, deferred);     // :49
+#ifdef ILQR_DEBUG_COUNTERS
+    if (EXACT && (threadIdx.x & 63) == 0) {
+        const unsigned long long dt = __builtin_readcyclecounter() - dbg_k0;
+        atomicAdd(&g_dbg[DEFER ? 13 : 14], dt);            // cycles of all wavefronts' passes, first / second launch
+        atomicMax(&g_dbg[15], dt);                         // the longest pass of a wavefront
+        atomicAdd(&g_dbg[DEFER ? 6 : 7], 1ull);
+    }
+#endif
+    if constexpr (DEFER) {
+        // dropped from this launch: nothing of the pass is kept, the next launch of this iteration runs it again
+        const int k = wave_append(live && deferred, a.cnt + CNT_DEFER);
+        if (live && deferred) {
+            a.defer[k] = s;
+            a.dirty[id] = 1;
+        }
+        live = live && !deferred;
+    }
     if (live) {
+        if constexpr (EXACT) a.dirty[id] = dirty ? 1 : 0;
         a.iters[id] = it;
         a.maxq[id] = maxq;
         a.regu_rounds[id] += rr;
@@ -265,7 +307,9 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
             copy_traj<M>(T, final_dest<M>(a, id), S);
     }
     const int j = wave_append(need_ls, a.cnt + 1);
-    const int ns = wave_append(cont, a.cnt + 0);
+    const int nfront = wave_append(cont && !dirty, a.cnt + 0);
+    const int nback = wave_append(cont && dirty, a.cnt + CNT_DIRTY);
+    const int ns = dirty ? (int)a.B - 1 - nback : nfront;
     bool side = false;
     if (need_ls) {
         a.ls_slot[j] = s;

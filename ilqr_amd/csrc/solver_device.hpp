@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "eig_device.hpp"
+#include "eig_screen.hpp"
 #include "models.hpp"
 
 namespace ilqr {
@@ -455,6 +456,59 @@ __device__ __forceinline__ void fill_full(const eig::Lane<n + m, 64>& E, const d
             E.A(i + 1, j + 1) = v;
         }
 }
+// the same matrix entry by entry, for eig::screen
+template <int n, int m>
+struct PackedFull {
+    const double* L;
+    const double* U;
+    __device__ __forceinline__ double operator()(int i, int j) const
+    {
+        using QP = QPack<n, m>;
+        if (i >= j) return L[tri(i, j)];
+        if (j < n) return U[upp(n, i, j)];
+        if (i >= n) return U[upp(m, i - n, j - n, QP::UUB)];
+        return L[tri(j, i)];
+    }
+};
+// `np.any(np.linalg.eigvals(Q) < 0)` the way NumPy decides it, for the lane's matrix (L, U): the certified screen
+// first, LAPACK's path (eig_device.hpp) for the lanes it leaves in doubt.  `doubt` says which way this lane went.
+// Called by all lanes together; the LAPACK path is skipped by the wavefront when no lane needs it.
+#ifdef ILQR_DEBUG_COUNTERS
+// build-time diagnostics (tools/debug_counters.py): [2 site] calls of exact_negative by a wavefront, [2 site + 1] those
+// in which some lane took LAPACK's path; sites 0 round 0, 1 group scan, 2 stuck scan; [8] lanes in doubt, summed
+static __device__ unsigned long long g_dbg[16];
+#define ILQR_DBG_SITE(k) , (k)
+#else
+#define ILQR_DBG_SITE(k)
+#endif
+template <int n, int m>
+__device__ __forceinline__ int exact_negative(const eig::Lane<n + m, 64>& E, const double* L, const double* U, bool want,
+                                              bool& doubt
+#ifdef ILQR_DEBUG_COUNTERS
+                                              , int site
+#endif
+)
+{
+    // (a lane whose verdict nobody will read -- no trajectory, or one that has dropped out -- never asks for LAPACK's path)
+    int v = eig::screen<n + m>(PackedFull<n, m>{L, U});
+    doubt = want && (v == eig::SCREEN_DOUBT);
+    v = want ? v : eig::SCREEN_NONE;
+#ifdef ILQR_DEBUG_COUNTERS
+    {
+        const unsigned long long db = __ballot(doubt);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&g_dbg[2 * site], 1ull);
+            if (db) atomicAdd(&g_dbg[2 * site + 1], 1ull);
+            atomicAdd(&g_dbg[8 + site], (unsigned long long)__popcll(db));
+        }
+    }
+#endif
+    if (doubt) {
+        fill_full<n, m>(E, L, U);
+        v = E.has_negative();
+    }
+    return v;
+}
 // largest |entry| of a packed lower triangle joined to mq (a NaN entry never wins)
 template <int NL>
 __device__ __forceinline__ double max_abs_packed(const double* L, double mq)
@@ -510,10 +564,13 @@ __device__ __forceinline__ double running_sum(double v, double p, int k0, int co
 // lane carries a trajectory); `lds` holds stage_lds_doubles() doubles.
 // Returns false on the LinAlgError cases.
 // ------------------------------------------------------------------
-template <class M, bool EXACT = false>
+// DEFER (with EXACT): a trajectory that is still failing after the group scan is not scanned further here: it is
+// reported in `deferred` and drops out of this pass (the caller runs its pass again in a launch whose wavefronts hold few
+// trajectories each, so that the long scans of different trajectories do not queue up in one wavefront).
+template <class M, bool EXACT = false, bool DEFER = false>
 __device__ __forceinline__ bool backward_stage(const double* par, double* xu, const double* next, double* Vx, double* V,
                                       double* dk, double* Kk, double& redu, int& regu_rounds, int& regu_stages,
-                                      double& maxq, bool alive, double* lds)
+                                      double& maxq, bool alive, double* lds, bool& dirty, bool& deferred)
 {
     const double* const xk = xu;
     const double* const uk = xu + M::NX;
@@ -556,8 +613,9 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
         int neg;
         if constexpr (EXACT) {
             maxq = max_abs_packed<NL>(QL, maxq);
-            fill_full<n, m>(E, QL, QU);
-            neg = E.has_negative();
+            bool doubt;
+            neg = exact_negative<n, m>(E, QL, QU, alive, doubt ILQR_DBG_SITE(0));
+            dirty = dirty || (alive && doubt);
         } else {
             neg = has_negative_eig_packed<w, UF>(QL, maxq);
         }
@@ -597,6 +655,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
         wave_sync();
         int t = 1;
         double mq = 0.0;
+        bool gdoubt = false;
         if (g < nsrc) {
             double L[NL];
             if constexpr (!EXACT) build_regularised<NL>(L, regu_coef(c + 1), ldsP + g * NL, park - lane + srcs[g]);
@@ -608,14 +667,14 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
                 ILQR_UNROLL
                 for (int e = 0; e < NUP; ++e) U[e] = running_sum(ldsQU[g * NUP + e], ldsPU[g * NUP + e], 0, c + 1);
                 mq = max_abs_packed<NL>(L, mq);
-                fill_full<n, m>(E, L, U);
-                t = E.has_negative();
+                t = exact_negative<n, m>(E, L, U, true, gdoubt ILQR_DBG_SITE(1));
             } else {
                 t = has_negative_eig_packed<w, UF>(L, mq);
             }
         }
         // first passing round of every group, its verdict, and the largest |Q| met up to it
         const unsigned long long passed = __ballot(t != 1);
+        const unsigned long long gdoubts = EXACT ? __ballot(gdoubt) : 0ull;
         ILQR_UNROLL
         for (int dlt = 1; dlt < REGU_BASE; dlt *= 2) {
             const double up = __shfl_up(mq, dlt, REGU_BASE);
@@ -629,6 +688,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
         wave_sync();
         if (src) {
             maxq = fmax(maxq, mqs);
+            if constexpr (EXACT) dirty = dirty || (((gdoubts >> (REGU_BASE * rank)) & ((1u << REGU_BASE) - 1u)) != 0);
             r = (cstar >= 0) ? cstar + 1 : REGU_BASE;
             if (cstar >= 0) {
                 const double coef = regu_coef(r);
@@ -663,7 +723,9 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
                 }
                 ok = ok && (tt >= 0);
             } else {
-                stuck_here = true;      // Q(0) stays in the park: the stuck scan builds every round from it
+                if constexpr (DEFER) deferred = true;
+                else stuck_here = true;      // Q(0) stays in the park: the stuck scan builds every round from it
+                if constexpr (EXACT) dirty = true;
             }
             need = false;
         }
@@ -672,6 +734,10 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
 
     // ---- stuck scan: rounds REGU_BASE + 1, + 2, ... of one trajectory, 64 at a time
     unsigned long long stuck = __ballot(stuck_here);
+#ifdef ILQR_DEBUG_COUNTERS
+    const unsigned long long dbg_t0 = __builtin_readcyclecounter();
+    const bool dbg_any = stuck != 0;
+#endif
     while (stuck) {
         const int src = __ffsll((long long)stuck) - 1;
         stuck &= stuck - 1;
@@ -705,6 +771,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
             for (int base = REGU_BASE + 1;; base += 64) {
                 wave_sync();
                 double mq = 0.0;
+                int t;
                 {
                     double L[NL], U[NUP > 0 ? NUP : 1];
                     ILQR_UNROLL
@@ -712,9 +779,9 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
                     ILQR_UNROLL
                     for (int e = 0; e < NUP; ++e) U[e] = running_sum(ckU[e], ldsPU[e], base, lane);
                     mq = max_abs_packed<NL>(L, mq);
-                    fill_full<n, m>(E, L, U);
+                    bool sdoubt;
+                    t = exact_negative<n, m>(E, L, U, true, sdoubt ILQR_DBG_SITE(2));
                 }
-                const int t = E.has_negative();
                 const unsigned long long stops = __ballot(t != 1);
                 if (stops) {
                     const int win = __ffsll((long long)stops) - 1;
@@ -797,6 +864,9 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
             }
         }
     }
+#ifdef ILQR_DEBUG_COUNTERS
+    if (dbg_any && (threadIdx.x & 63) == 0) atomicAdd(&g_dbg[12], __builtin_readcyclecounter() - dbg_t0);     // cycles in stuck scans
+#endif
     regu_rounds += r;
     // No early return on the LinAlgError cases: the lane goes on with numbers nobody will read (the caller
     // drops the trajectory).  With a way out in the middle of the stage the old V_x, V_xx would have to stay
@@ -981,10 +1051,10 @@ struct Dest {
 // on.  Reads the T records, writes the G records; returns deltaJ and max_k |d_k|_2 (with NumPy's NaN propagation, as
 // np.max(np.linalg.norm(d, axis=1)) has).  Returns false on LinAlgError.
 // ------------------------------------------------------------------
-template <class M, bool EXACT = false>
+template <class M, bool EXACT = false, bool DEFER = false>
 __device__ __forceinline__ bool backward_pass(const double* par, const RecIn& T, const RecOut& G, int S, double& deltaJ,
                                      double& dmax, int& regu_rounds, int& regu_stages, double& maxq, bool active,
-                                     double* lds)
+                                     double* lds, bool& dirty, bool& deferred)
 {
     using TR = typename TermsOf<M>::type;
     constexpr int n = M::NDX, m = M::NU, nx = M::NX;
@@ -1000,10 +1070,10 @@ __device__ __forceinline__ bool backward_pass(const double* par, const RecIn& T,
     // loop has to allow for these loads on every trip and ends up waiting for the previous stage's stores.
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
     for (int k = S - 1; k >= 0; --k) {
-        const bool alive = active && ok;
+        const bool alive = active && ok && !deferred;
         // (the stage leaves the record of stage k - 1 in xu; the last one loads its own again)
-        const bool good = backward_stage<M, EXACT>(par, xu, T.p + (long)(k > 0 ? k - 1 : 0) * T.ss, Vx, V, dk, Kk, redu,
-                                            regu_rounds, regu_stages, maxq, alive, lds);
+        const bool good = backward_stage<M, EXACT, DEFER>(par, xu, T.p + (long)(k > 0 ? k - 1 : 0) * T.ss, Vx, V, dk, Kk, redu,
+                                            regu_rounds, regu_stages, maxq, alive, lds, dirty, deferred);
         ok = ok && good;
         // stored by every lane, whatever its state (a lane without a trajectory is given a scratch record by
         // the caller, a failed one writes gains nobody reads): a fixed number of stores, all younger than the

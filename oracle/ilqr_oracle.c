@@ -148,9 +148,15 @@ int ilqr_oracle_has_negative_eig_lapack(const double *Q, int w, double *W)
  * statistically on ill-conditioned solves, where the two rules part and no trajectory is reproducible one by one. */
 static int g_psd_rule = 0;
 void ilqr_oracle_set_psd_rule(int rule) { g_psd_rule = rule; }
+/* Diagnostics: a function the tests may register to see every (matrix, verdict) pair the solver decides
+ * (row-major w x w, verdict as returned below); called from the solver's OpenMP threads. */
+static void (*g_eig_observer)(const double *Q, int w, int verdict) = 0;
+void ilqr_oracle_set_eig_observer(void (*fn)(const double *, int, int)) { g_eig_observer = fn; }
 int ilqr_oracle_has_negative_eig(const double *Q, int w, double *W)
 {
-    return g_psd_rule == 1 ? ilqr_oracle_has_negative_eig_ldl(Q, w, W) : ilqr_oracle_has_negative_eig_lapack(Q, w, W);
+    const int v = g_psd_rule == 1 ? ilqr_oracle_has_negative_eig_ldl(Q, w, W) : ilqr_oracle_has_negative_eig_lapack(Q, w, W);
+    if (g_eig_observer) g_eig_observer(Q, w, v);
+    return v;
 }
 
 /* np.linalg.inv for m <= ILQR_MAX_NU: Gauss-Jordan with partial pivoting.

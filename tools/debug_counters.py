@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""How often the wavefronts of a faithful (ILQR_FLAG_LAPACK_EIGVALS) car solve take LAPACK's path, per site, from a
+diagnostics build of the library:
+    python -c "from ilqr_amd import build as r; r.build_library('ilqr_amd/lib/libilqr_hip_dbg.so', defines=['ILQR_DEBUG_COUNTERS'])"
+    ILQR_HIP_LIB=ilqr_amd/lib/libilqr_hip_dbg.so python tools/debug_counters.py [batch]
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from ilqr_amd import _lib  # noqa: E402
+from ilqr_amd.batch import BatchSolver  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+max_iter = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+dev = torch.device("cuda:0")
+s = BatchSolver(0, [2.0, 2.0], 40, max_iter, 20, 1e-3, device=dev, flags=_lib.FLAG_LAPACK_EIGVALS | _lib.FLAG_SINGLE_STREAM)
+x0, u0 = bench.car_inputs(B, 1234)
+L = s.lib
+out = (C.c_ulonglong * 16)()
+L.ilqr_debug_counters(out, 1)
+r = s.solve(x0, u0)
+torch.cuda.synchronize()
+L.ilqr_debug_counters(out, 1)
+v = list(out)
+for k, name in enumerate(("round 0", "group scan", "stuck scan")):
+    print(f"{name:11s}: wavefront calls {v[2 * k]:10d}, with LAPACK {v[2 * k + 1]:10d} ({v[2 * k + 1] / max(v[2 * k], 1):.3f}), "
+          f"lanes in doubt per call {v[8 + k] / max(v[2 * k], 1):.2f}")
+trips = max(v[4], 1)
+print(f"stuck scans: {v[12] / 1e6:.1f} Mcycles in total, {v[12] / trips:.0f} cycles per 64-round trip")
+print(f"passes of wavefronts: first launches {v[6]} passes, {v[13] / max(v[6], 1):.0f} cycles each; second launches {v[7]} passes, "
+      f"{v[14] / max(v[7], 1):.0f} cycles each; longest pass {v[15]} cycles")
