@@ -391,7 +391,12 @@ def main():
                 # the 1e-14 perturbation where that is more
                 bar = np.maximum(1e-8, 100.0 * drift)[repro & same] if (repro & same).any() else np.array([np.nan])
                 calm = i1["max_abs_q"] < 1e5
-                res["parity_check"] = {"checked": int(c), "reproducible": int(repro.sum()),
+                # the reproducible solves that are NOT within 1e-8, one by one
+                idx = np.where(repro & same)[0]
+                beyond = [dict(index=int(b), rel_x_err=float(err[b]), checker_own_drift=float(drift[b]),
+                               exit=co.EXIT_NAMES[int(st[b])], iters=int(it[b]), max_abs_q=float(i1["max_abs_q"][b]))
+                          for b in idx[err[idx] > 1e-8][:16]]
+                res["parity_check"] = {"beyond_1e-8": beyond,"checked": int(c), "reproducible": int(repro.sum()),
                                        "reproducible_same_decisions": int((repro & same).sum()),
                                        "max_rel_x_err_reproducible": float(np.nanmax(sel)),
                                        "median_rel_x_err_reproducible": float(np.nanmedian(sel)),

@@ -499,6 +499,28 @@ def gen_variants(pool):
     run_cases("quad_quat_fullw_N30", spec, sp, Xq, Ue, pool)
 
 
+def gen_near_goal(pool):
+    """Both quadrotors from starts a few centimetres and hundredths of a radian from hover, controls within 0.05 of
+    the hover thrust, at a horizon of 16 knots.  The reference's backward pass never symmetrises V_xx, and for these
+    plants (dt = 0.01, R = 0.02) the antisymmetric part of V_xx grows by a factor of about 2.3 per stage: rounding noise
+    of 2e-16 at the last stage is 1e-4 of V_xx forty stages earlier, which is why not one of the N = 40 solves from hover
+    is reproduced by the reference to 1e-8 under a 1e-14 perturbation of its inputs (`stable` 0 of 16), however easy the
+    solve.  Sixteen knots keep that growth below 1e-9, so these solves pin x, u and J of the 12-state kernels at the
+    1e-8 bar itself."""
+    rng = np.random.default_rng(55)
+    B = 32
+    sp = dict(N=16, max_iter=20, max_ls=10, d_tol=5e-4)
+    Xe = np.zeros((B, 12)); Xe[:, 2] = 1.0 + 0.05 * rng.standard_normal(B); Xe[:, :2] = 0.05 * rng.standard_normal((B, 2))
+    Xe[:, 3:6] = 0.02 * rng.standard_normal((B, 3)); Xe[:, 6:9] = 0.02 * rng.standard_normal((B, 3))
+    Ue = 1.9006875 + 0.05 * rng.standard_normal((B, 15, 4))
+    run_cases("quad_ea_near_N16", ea_spec(16), sp, Xe, Ue, pool)
+    Xq = np.zeros((B, 13)); Xq[:, 6] = 1.0 + 0.05 * rng.standard_normal(B); Xq[:, 4:6] = 0.05 * rng.standard_normal((B, 2))
+    Xq[:, 10:13] = 0.02 * rng.standard_normal((B, 3))
+    for b in range(B):
+        Xq[b, :4] = euler_zyx_to_quat(0.02 * rng.standard_normal(3))
+    run_cases("quad_quat_near_N16", quat_spec(16), sp, Xq, Ue, pool)
+
+
 def gen_units(pool):
     """Pure functions of the reference solver on random blocks (iLQRController.py:125-147, model.py:45-53)."""
     from control.iLQRController import iLQR
@@ -580,7 +602,7 @@ def gen_quat_utils(pool):
 
 
 GENS = dict(quat_utils=gen_quat_utils, user_rover=gen_user_rover, user_tug=gen_user_tug, user_compass=gen_user_compass, car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
-            acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat, baseline=gen_baseline_horizons, variants=gen_variants, units=gen_units)
+            acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat, baseline=gen_baseline_horizons, variants=gen_variants, near_goal=gen_near_goal, units=gen_units)
 
 
 def main():

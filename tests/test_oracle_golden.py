@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, load_golden
-from helpers import compare_to_golden, cost_horizon, min_compared, model_key
+from helpers import compare_to_golden, cost_horizon, min_compared, min_within_1e8, model_key
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -16,6 +16,7 @@ def test_oracle_matches_reference_golden(oracle, name):
     n = compare_to_golden(g, r["x"], r["u"], i["J_last"], i["iters"], i["status"], i["ls_evals"], i["accepted"],
                           i["regu_rounds"], J0=i["J0"], label=name)
     assert n >= min_compared(name, g), (name, n)
+    assert n.within_1e8 >= min_within_1e8(name, g), (name, n.within_1e8, n.stable)
     if name in ("car_readme", "car_mpc50", "car_dtol", "car_maxiter2", "car_maxls1", "car_N2", "acrobot_N40",
                 "car_circle_N60", "quad_ea_N30", "quad_quat_N30"):
         assert n == len(g["iters"])      # every trajectory of these fixtures is compared
