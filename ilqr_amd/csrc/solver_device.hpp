@@ -522,6 +522,12 @@ __device__ __forceinline__ double max_abs_packed(const double* L, double mq)
 #ifndef ILQR_BUILD_CHUNK
 #define ILQR_BUILD_CHUNK 8
 #endif
+// ILQR_PHASE_MARKERS (tools/stage_budget.py): named comments in the assembly at the phase boundaries of a stage
+#ifdef ILQR_PHASE_MARKERS
+#define ILQR_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; ILQR_MARK " #name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ILQR_MARK(name) ((void)0)
+#endif
 #ifdef ILQR_NO_PHASE_BARRIER
 #define ILQR_PHASE_BARRIER() ((void)0)
 #else
@@ -590,6 +596,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
     double* const ldsQU = exact0 + (w * w + 2 * w) * 64;                                  // Q(0) above the diagonal
     double* const ldsPU = ldsQU + (REGU_GROUPS * (NUP > 0 ? NUP : 1) + 1) / 2 * 2;          // P above the diagonal
     double PUown[NUP > 0 ? NUP : 1];       // EXACT: this lane's own P above the diagonal, for the accepted round
+    ILQR_MARK(terms);
     {
         double aux[TR::AUX];
         TR::backward_terms(par, xk, uk, Vx, V, Qx, Qu, QL, QU, aux);
@@ -602,8 +609,10 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
         for (int e = 0; e < TR::AUX; ++e) park[(NL + e) * 64] = aux[e];
     }
     ILQR_PHASE_BARRIER();
+    ILQR_MARK(load_next);
     load_rec<M::NX + M::NU>(next, xu);
     ILQR_PHASE_BARRIER();
+    ILQR_MARK(round0);
 
     bool ok = true;
     int r = 0;
@@ -627,6 +636,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
     bool stuck_here = false;
 
     // ---- group scan: rounds 1..REGU_BASE of up to REGU_GROUPS trajectories at once
+    ILQR_MARK(group_scan);
     unsigned long long pend = __ballot(need);
     const unsigned long long below = (1ull << lane) - 1ull;
     const int g = lane / REGU_BASE, c = lane % REGU_BASE;         // this lane tests trajectory g after c + 1 rounds
@@ -653,6 +663,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
             }
         }
         wave_sync();
+        ILQR_MARK(group_test);
         int t = 1;
         double mq = 0.0;
         bool gdoubt = false;
@@ -673,6 +684,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
             }
         }
         // first passing round of every group, its verdict, and the largest |Q| met up to it
+        ILQR_MARK(group_select);
         const unsigned long long passed = __ballot(t != 1);
         const unsigned long long gdoubts = EXACT ? __ballot(gdoubt) : 0ull;
         ILQR_UNROLL
@@ -733,6 +745,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
     }
 
     // ---- stuck scan: rounds REGU_BASE + 1, + 2, ... of one trajectory, 64 at a time
+    ILQR_MARK(stuck_scan);
     unsigned long long stuck = __ballot(stuck_here);
 #ifdef ILQR_DEBUG_COUNTERS
     const unsigned long long dbg_t0 = __builtin_readcyclecounter();
@@ -872,6 +885,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
     // drops the trajectory).  With a way out in the middle of the stage the old V_x, V_xx would have to stay
     // in registers through the factorisations for the sake of that path alone.
     ILQR_PHASE_BARRIER();
+    ILQR_MARK(gains_v);
     ILQR_UNROLL
     for (int e = 0; e < NL; ++e) QL[e] = park[e * 64];      // Q(r)
 
@@ -943,6 +957,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
         eb += (0.5 * dk[a]) * s;
     }
     redu += ea - eb;
+    ILQR_MARK(stage_end);
     return ok;
 }
 
