@@ -194,12 +194,6 @@ int check_problem(const ilqr_problem* p, ModelDims& d)
     if (p->max_iter < 0 || p->max_ls < 0 || p->trace_len < 0) return fail(ILQR_E_BADARG, "negative count");
     if (p->cost_N < 0 || p->cost_N > p->N) return fail(ILQR_E_BADARG, "cost_N must be 0 (= N) or within 1..N");
     if (p->reserved_ != 0) return fail(ILQR_E_BADARG, "ilqr_problem.reserved_ must be 0 (a caller built against another header?)");
-    if ((p->flags & ILQR_FLAG_LAPACK_EIGVALS) && d.ndx + d.nu > 8) {
-        const bool quad = p->model_id == ILQR_MODEL_QUAD_EA || p->model_id == ILQR_MODEL_QUAD_QUAT;
-        if (!quad || (p->flags & ILQR_FLAG_PARAMS_PER_TRAJECTORY))
-            return fail(ILQR_E_BADARG, "ILQR_FLAG_LAPACK_EIGVALS: among the 12-state plants it is built for the two "
-                                       "quadrotors with one parameter block for the batch");
-    }
     if ((p->flags & ILQR_FLAG_LS_SEQUENTIAL) && p->max_ls > 60)
         return fail(ILQR_E_BADARG, "ILQR_FLAG_LS_SEQUENTIAL supports max_ls <= 60");
     return ILQR_OK;

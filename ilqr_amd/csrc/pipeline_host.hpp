@@ -124,7 +124,7 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
         if constexpr (M::TEAM_BACKWARD) {
             if constexpr (team_exact_built<M, PT>()) {
                 if (a.flags & ILQR_FLAG_LAPACK_EIGVALS)
-                    hipLaunchKernelGGL((pipe_backward_team_kernel<M, false, true>), dim3(blocks_for(count, PIPE_WG / TEAM_LANES)),
+                    hipLaunchKernelGGL((pipe_backward_team_kernel<M, PT, true>), dim3(blocks_for(count, PIPE_WG / TEAM_LANES)),
                                        dim3(PIPE_WG), 0, st, a);
                 else
                     hipLaunchKernelGGL((pipe_backward_team_kernel<M, PT>), dim3(blocks_for(count, PIPE_WG / TEAM_LANES)),

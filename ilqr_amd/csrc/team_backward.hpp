@@ -495,11 +495,12 @@ __device__ __forceinline__ void team_regularise_exact(double* Qrow, double* Prow
     }
 }
 
-// The exact kernel is built for the two quadrotor plants with one parameter block for the batch.
+// The exact kernel is built for every plant the 16-lane kernel solves, with one parameter block for the batch or one
+// per trajectory.
 template <class M, bool PT>
 constexpr bool team_exact_built()
 {
-    return !PT && (std::is_same_v<M, QuadEAModel> || std::is_same_v<M, QuadQuatModel>);
+    return true;
 }
 
 // PT: one parameter block per trajectory (at a.par + id * a.par_block) instead of one for all.

@@ -107,9 +107,8 @@ enum {
      * indefinite for tens of rounds more, and this flag reproduces the reference's exit classes and iteration
      * counts as a population.  In this mode the regularised matrix is also accumulated round by round like the
      * reference's `Q += regu * f'f` (:111-115) and P = (0.1 f)'f is formed like NumPy's matrix product.  An eigenvalue
-     * computation per test instead of a factorisation: several hundred times slower on the headline batch.  Car,
-     * acrobot, user-defined plants with ndx + nu <= 8, and the two quadrotors with one parameter block for the batch;
-     * refused (ILQR_E_BADARG) for wider user-defined plants and for quadrotors with ILQR_FLAG_PARAMS_PER_TRAJECTORY. */
+     * computation per test wherever a cheaper certified bound does not settle the sign: tens of times slower on
+     * the headline batch.  Every plant and every parameter layout the library solves. */
     ILQR_FLAG_LAPACK_EIGVALS = 32,
     /* Run every iteration.  By default a solve that has reached a state from which every further iteration repeats the
      * last one exactly is not iterated to max_iter: the counters, traces and exit status those iterations would leave

@@ -42,6 +42,12 @@ def test_hip_matches_reference_golden(torch_gpu, name):
     assert n.within_1e8 >= min_within_1e8(name, g), (name, n.within_1e8, n.stable)
 
 
+def torch_equal(a, b):
+    """Bit for bit, NaNs in the same places."""
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    return np.array_equal(a, b, equal_nan=a.dtype.kind == "f")
+
+
 def _car_box(rng, B):
     return np.column_stack([rng.uniform(-4, 4, B), rng.uniform(-4, 4, B), rng.uniform(-np.pi, np.pi, B),
                             rng.uniform(0, 3, B), rng.uniform(-0.3, 0.3, B)])
@@ -620,7 +626,7 @@ def test_lapack_eigvals_flag_on_the_quadrotor_fixtures(torch_gpu, oracle):
     """ILQR_FLAG_LAPACK_EIGVALS in the 16-lanes-per-trajectory kernel.  On the reproducible fixtures the decisions are
     the reference's one by one, as with the default rule; on the contract's configurations 3 and 4 far from hover
     (status-class fixtures, 16 solves each) the exits are compared with the reference's as classes, and a per-trajectory
-    parameter block with the flag is refused."""
+    parameter block with the flag gives the bits of the shared block."""
     from ilqr_amd import _lib
     from ilqr_amd.batch import BatchSolver
     for name in ("quad_ea_N30", "quad_quat_N30", "quad_ea_hover_N40", "quad_quat_hover_N40", "quad_quat_fullw_N30",
@@ -640,11 +646,18 @@ def test_lapack_eigvals_flag_on_the_quadrotor_fixtures(torch_gpu, oracle):
               % (r["iters"].mean(), g["iters"].mean()))
         assert same >= 0.6, (name, r["status"], g["status"])
         assert abs(r["iters"].mean() - g["iters"].mean()) <= 0.3 * g["iters"].mean(), name
-    g = load_golden("quad_ea_N30")
-    B = len(g["x0"])
-    with pytest.raises(Exception, match="LAPACK_EIGVALS"):
-        BatchSolver(2, np.tile(np.asarray(g["par"], dtype=np.float64), (B, 1)), int(g["N"]), 5, 5, 1e-3,
-                    flags=_lib.FLAG_LAPACK_EIGVALS | _lib.FLAG_PARAMS_PER_TRAJECTORY).solve(g["x0"], g["u_init"])
+    # a parameter block per trajectory with the flag: the same bits as the shared block (both quadrotors; fixtures that
+    # regularise, so that the scans of the LAPACK path run)
+    for name, mid in (("quad_ea_N30", 2), ("quad_quat_fullw_N30", 3), ("quad_quat_hover_N40", 3)):
+        g = load_golden(name)
+        B = len(g["x0"])
+        sp = (int(g["N"]), int(g["max_iter"]), int(g["max_ls"]), float(g["d_tol"]))
+        par = np.asarray(g["par"], dtype=np.float64)
+        a = BatchSolver(mid, par, *sp, flags=_lib.FLAG_LAPACK_EIGVALS, cost_N=cost_horizon(g)).solve(g["x0"], g["u_init"])
+        b = BatchSolver(mid, np.tile(par, (B, 1)), *sp, flags=_lib.FLAG_LAPACK_EIGVALS,
+                        cost_N=cost_horizon(g)).solve(g["x0"], g["u_init"])
+        for k in ("x", "u", "J", "iters", "status", "regu_rounds", "ls_total", "max_abs_q"):
+            assert torch_equal(getattr(a, k), getattr(b, k)), (name, k)
 
 
 def test_line_search_counters_and_plant_horizon(torch_gpu):

@@ -100,3 +100,46 @@ def test_lqr_controller_stabilises_the_quadrotors_about_hover(oracle):
     from ilqr_amd import CarModel
     with pytest.raises(RuntimeError):          # car.py states its step only
         CarModel(2, 2)._linearize_continuous(np.zeros(5), np.zeros(2))
+
+
+@pytest.mark.gpu
+def test_lqr_controller_balances_the_acrobot_upright(oracle):
+    """AcrobotLQRController (control/AcrobotControllers.py:68-115): the acrobot linearised at the upright goal with
+    u = 0, gain from the discrete or the continuous Riccati equation with the plant's own Q and R, u = -K (x - goal).
+    The Jacobians come from the GPU library and are checked against the checker's (hand-written dynamics, forward-mode
+    AD); the closed loop on the nonlinear plant returns to the goal from a displaced start in both modes."""
+    import ctypes as C
+    from ilqr_amd import Acrobot2DModel
+    from ilqr_amd.lqr import LQRController
+    Q = np.diag([10.0, 10.0, 1.0, 1.0]); R = np.array([[1.0]])
+    plant = Acrobot2DModel(Q, 100.0 * np.eye(4), R, 0.01, 50)
+    goal = np.array([np.pi, 0.0, 0.0, 0.0])
+    u0 = np.zeros(1)
+    A, B = plant._linearize_discrete(goal, u0)
+    e = oracle.eval_point("acrobot", plant._param_block(), goal, u0)
+    assert A.shape == (4, 4) and B.shape == (4, 1)
+    assert np.allclose(A, e["f_x"], rtol=1e-10, atol=1e-12) and np.allclose(B, e["f_u"], rtol=1e-10, atol=1e-12)
+    assert np.abs(np.linalg.eigvals(A)).max() > 1.0            # upright is unstable without control
+    L = oracle.lib()
+    L.oracle_acrobot_xdot_jac.restype = None
+    dp = C.POINTER(C.c_double)
+    xq = goal + 0.2 * np.random.default_rng(8).standard_normal(4)
+    uq = np.array([0.3])
+    f, Ao, Bo = np.zeros(4), np.zeros((4, 4)), np.zeros((4, 1))
+    L.oracle_acrobot_xdot_jac(*(v.ctypes.data_as(dp) for v in (xq, uq, f, Ao, Bo)))
+    Ac, Bc = plant._linearize_continuous(xq, uq)
+    assert np.allclose(Ac, Ao, rtol=1e-10, atol=1e-11) and np.allclose(Bc, Bo, rtol=1e-10, atol=1e-11)
+    for mode in ("discrete", "continuous"):
+        ctl = LQRController(plant, mode=mode)          # the plant's own Q, R; uref = 0 as in the reference
+        K = ctl.gain(goal)
+        assert K.shape == (1, 4)
+        if mode == "discrete":
+            assert np.abs(np.linalg.eigvals(A - B @ K)).max() < 1.0
+        else:
+            Ag, Bg = plant._linearize_continuous(goal, u0)
+            assert np.linalg.eigvals(Ag - Bg @ K).real.max() < 0.0
+        x = goal + np.array([0.05, -0.04, 0.0, 0.0])
+        d0 = np.linalg.norm(x - goal)
+        for _ in range(1500):
+            x = plant.discrete_dynamics(x, ctl.control(x, goal))
+        assert np.linalg.norm(x - goal) < 0.02 * d0, (mode, x - goal)

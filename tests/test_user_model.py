@@ -287,6 +287,23 @@ def test_wide_user_plant_on_gpu_matches_reference_golden(tug_gpu):
 
 
 @pytest.mark.gpu
+def test_wide_user_plant_with_lapacks_eigenvalue_rule(tug_gpu):
+    """ILQR_FLAG_LAPACK_EIGVALS for a plant solved by the 16-lane kernels through TeamOps<UserModel>: every solve of
+    the reference's fixture regularises, and with the reference's own eigenvalue test the decisions stay the reference's."""
+    from ilqr_amd.iLQRController import iLQR
+    g = load_golden("user_tug")
+    tug_gpu.set_params(g["par"])
+    ctl = iLQR(tug_gpu, int(g["N"]), int(g["max_iter"]), int(g["max_ls"]), float(g["d_tol"]), trace_len=64, eigvals="lapack")
+    x, u = ctl.run_ilqr(np.array(g["x0"]), np.array(g["u_init"], copy=True))
+    info, t = ctl.info, ctl.info.traces
+    assert (g["regu_rounds"] > 0).all()
+    n = compare_to_golden(g, x, u, info.J.cpu().numpy(), info.iters.cpu().numpy(), info.status.cpu().numpy(),
+                          t["ls_evals"].cpu().numpy(), t["accepted"].cpu().numpy(), info.regu_rounds.cpu().numpy(),
+                          J0=info.J0.cpu().numpy(), label="user_tug (LAPACK's rule)")
+    assert n >= 28
+
+
+@pytest.mark.gpu
 def test_wide_user_plant_batch_and_model_interface_on_gpu(oracle, tug_gpu):
     par = np.array([1.5, -1.0, 0.6, -0.4])
     tug_gpu.set_params(par)
