@@ -192,10 +192,15 @@ HEADER = """/* GENERATED by tools/gen_models.py -- do not edit.
 # ---------------------------------------------------------------------------
 # plants defined by the user
 # ---------------------------------------------------------------------------
-def user_expressions(nx, nu, n_par, dynamics, cost_stage, cost_final, diff_state=None):
+def user_expressions(nx, nu, n_par, dynamics, cost_stage, cost_final, diff_state=None, ndx=None, overrides=None):
     """Run the user's functions once on SymPy symbols: dynamics(x, u, p), cost_stage(x, u, p), cost_final(x, p) and,
     if the plant overrides CalcDifferentialState (control/models/model.py:22-23), diff_state(state, ref_state, p).
-    Returns (xs, us, ps, f [nx], l, lf), with a seventh entry (ss, rs, dx [nx]) when diff_state is given."""
+    Returns (xs, us, ps, f, l, lf), with a seventh entry (ss, rs, dx) when diff_state is given.
+
+    A plant whose error state has another dimension than its state (ndx != nx: control/models/Quadrotor_Quat.py) also
+    overrides stage, final and Q_terms (:248-275); `overrides` = dict(stage=, final=, q_terms=) holds them as functions
+    of symbols plus p, and an eighth entry carries what they returned: dict(stage=[l_x, l_u, l_xx, l_ux, l_uu, f_x, f_u],
+    final=[V_x, V_xx], q=[Q_x, Q_u, Q_xx, Q_ux, Q_uu], q_in=the symbols Q_terms was called with)."""
     if nx + nu > MAX_USER_W and (nx > WIDE_NX or nu > WIDE_NU):
         raise NotImplementedError(
             f"nx = {nx}, nu = {nu}: plants with nx + nu > {MAX_USER_W} are solved by the kernels built for "
@@ -218,11 +223,44 @@ def user_expressions(nx, nu, n_par, dynamics, cost_stage, cost_final, diff_state
     rs = sp.symbols(f"r0:{nx}", real=True)
     dx = sp.Matrix([sp.sympify(e) for e in np.asarray(diff_state(np.array(ss, dtype=object), np.array(rs, dtype=object), p),
                                                        dtype=object).ravel()])
-    if dx.shape[0] != nx:
+    ndx = nx if ndx is None else int(ndx)
+    if dx.shape[0] != ndx:
+        raise ValueError(f"CalcDifferentialState returned {dx.shape[0]} components, the plant declares ndx = {ndx}")
+    if ndx == nx and not overrides:
+        return xs, us, ps, f, l, lf, (ss, rs, dx)
+    if not overrides or any(k not in overrides for k in ("stage", "final", "q_terms")):
         raise NotImplementedError(
-            f"CalcDifferentialState returned {dx.shape[0]} components for nx = {nx}: an error state of another dimension "
-            "needs the plant's own Q_terms as well (Quadrotor_Quat.py:267-275), which is not traced")
-    return xs, us, ps, f, l, lf, (ss, rs, dx)
+            f"an error state of another dimension than the state (ndx = {ndx}, nx = {nx}) needs the plant's own stage, final "
+            "and Q_terms as well (Quadrotor_Quat.py:248-275)")
+    if nx + nu > MAX_USER_W:
+        raise NotImplementedError("plants with their own Q_terms are solved one trajectory per lane: nx + nu <= "
+                                  f"{MAX_USER_W}")
+
+    def mat(v, rows, cols, what):
+        a = np.asarray(v, dtype=object)
+        if a.size != rows * cols:
+            raise ValueError(f"{what}: {a.shape} where {rows} x {cols} is expected")
+        return sp.Matrix(rows, cols, [sp.sympify(e) for e in a.ravel()])
+
+    st = overrides["stage"](x, u, p)
+    shapes = [(nx, 1), (nu, 1), (nx, nx), (nu, nx), (nu, nu), (ndx, ndx), (ndx, nu)]
+    names = ["l_x", "l_u", "l_xx", "l_ux", "l_uu", "f_x", "f_u"]
+    stage = [mat(v, r, c, "stage() " + k) for v, (r, c), k in zip(st, shapes, names)]
+    fin = overrides["final"](x, p)
+    final = [mat(fin[0], ndx, 1, "final() V_x"), mat(fin[1], ndx, ndx, "final() V_xx")]
+    # Q_terms on symbols for every argument: what it does with them is the plant's own
+    q_in = dict(l_x=sp.symbols(f"lx0:{nx}", real=True), l_u=sp.symbols(f"lu0:{nu}", real=True),
+                l_xx=sp.symbols(f"lxx0:{nx * nx}", real=True), l_ux=sp.symbols(f"lux0:{nu * nx}", real=True),
+                l_uu=sp.symbols(f"luu0:{nu * nu}", real=True), f_x=sp.symbols(f"fx0:{ndx * ndx}", real=True),
+                f_u=sp.symbols(f"fu0:{ndx * nu}", real=True), V_x=sp.symbols(f"Vx0:{ndx}", real=True),
+                V_xx=sp.symbols(f"Vxx0:{ndx * ndx}", real=True))
+    arr = lambda k, shp: np.array(q_in[k], dtype=object).reshape(shp)
+    q = overrides["q_terms"](x, arr("l_x", (nx,)), arr("l_u", (nu,)), arr("l_xx", (nx, nx)), arr("l_ux", (nu, nx)),
+                             arr("l_uu", (nu, nu)), arr("f_x", (ndx, ndx)), arr("f_u", (ndx, nu)), arr("V_x", (ndx,)),
+                             arr("V_xx", (ndx, ndx)), p)
+    qs = [mat(q[0], ndx, 1, "Q_terms() Q_x"), mat(q[1], nu, 1, "Q_terms() Q_u"), mat(q[2], ndx, ndx, "Q_terms() Q_xx"),
+          mat(q[3], nu, ndx, "Q_terms() Q_ux"), mat(q[4], nu, nu, "Q_terms() Q_uu")]
+    return xs, us, ps, f, l, lf, (ss, rs, dx), dict(ndx=ndx, stage=stage, final=final, q=qs, q_in=q_in)
 
 
 def is_wide(nx, nu):
@@ -250,14 +288,15 @@ def pad_wide(nx, nu, exprs):
     return xp, up, ps, fp, lp, lf, (sp_, rp, dxp)
 
 
-CODEGEN_VERSION = "2"   # part of the library key: bump when the printed C or the solver sources change meaning
+CODEGEN_VERSION = "3"   # part of the library key: bump when the printed C or the solver sources change meaning
 
 
 def user_key(nx, nu, n_par, exprs):
     """Identity of a traced plant: dimensions and the canonical text of its three expressions."""
     xs, us, ps, f, l, lf = exprs[:6]
     text = "|".join([CODEGEN_VERSION, str(nx), str(nu), str(n_par), sp.srepr(f), sp.srepr(l), sp.srepr(lf)]
-                    + ([sp.srepr(exprs[6][2])] if len(exprs) > 6 else []))
+                    + ([sp.srepr(exprs[6][2])] if len(exprs) > 6 else [])
+                    + ([sp.srepr(m) for k in ("stage", "final", "q") for m in exprs[7][k]] if len(exprs) > 7 else []))
     return hashlib.sha256(text.encode()).hexdigest()[:12]
 
 
@@ -271,6 +310,7 @@ def generate_user_header(nx, nu, n_par, exprs, name="user"):
         nx, nu = WIDE_NX, WIDE_NU
     xs, us, ps, f, l, lf = exprs[:6]
     diff = exprs[6] if len(exprs) > 6 else None
+    own = exprs[7] if len(exprs) > 7 else None        # the plant's own stage / final / Q_terms (error-state plants)
     lx = sp.Matrix([l]).jacobian(xs)
     lu = sp.Matrix([l]).jacobian(us)
     lfx = sp.Matrix([lf]).jacobian(xs)
@@ -279,6 +319,10 @@ def generate_user_header(nx, nu, n_par, exprs, name="user"):
     out = out.replace("GENERATED by tools/gen_models.py", "GENERATED by ilqr_amd/codegen.py")
     out += f"#define USER_NX {nx}\n#define USER_NU {nu}\n#define USER_NP {max(1, n_par)}\n"
     out += f"#define USER_REAL_NX {real_nx}\n#define USER_REAL_NU {real_nu}\n"
+    out += f"#define USER_NDX {own['ndx'] if own else nx}\n"
+    if own:
+        out += ("#define USER_HAS_QTERMS 1   /* the plant's own stage, final and Q_terms on an error state "
+                "(Quadrotor_Quat.py:248-275) */\n")
     if wide:
         out += "#define USER_WIDE 1   /* stated with 12 states and 4 controls for the 16-lane backward kernel */\n"
     if diff is not None:
@@ -293,6 +337,15 @@ def generate_user_header(nx, nu, n_par, exprs, name="user"):
          "stage derivatives: l_x l_u l_xx l_ux l_uu f_x f_u (row-major)"),
         ("user_gen_final", ins[:2], [("V_x", lfx), ("V_xx", lfx.jacobian(xs))], "final-cost derivatives"),
     ]
+    if own:
+        names = ["l_x", "l_u", "l_xx", "l_ux", "l_uu", "f_x", "f_u"]
+        parts[3] = ("user_gen_stage", ins, list(zip(names, own["stage"])),
+                    "the plant's own stage(): l_x l_u l_xx l_ux l_uu on the state, f_x f_u on the error state (row-major)")
+        parts[4] = ("user_gen_final", ins[:2], [("V_x", own["final"][0]), ("V_xx", own["final"][1])], "the plant's own final()")
+        qi = own["q_in"]
+        parts.append(("user_gen_qterms", [("p", ps), ("x", xs)] + [(k, qi[k]) for k in
+                                                                   ("l_x", "l_u", "l_xx", "l_ux", "l_uu", "f_x", "f_u", "V_x", "V_xx")],
+                      list(zip(["Q_x", "Q_u", "Q_xx", "Q_ux", "Q_uu"], own["q"])), "the plant's own Q_terms()"))
     if diff is not None:
         parts.append(("user_gen_diff_state", [("p", ps), ("s", diff[0]), ("r", diff[1])], [("dx", diff[2])],
                       "CalcDifferentialState(state, ref_state)"))

@@ -91,7 +91,10 @@ struct CarModel {
 // constant zero, the added controls cost u^2/2 and move nothing) and takes the 16-lanes-per-trajectory backward
 // kernel of the quadrotors.
 struct UserModel {
-    static constexpr int NX = USER_NX, NU = USER_NU, NDX = USER_NX, NPAR = USER_NP;
+    // USER_NDX differs from USER_NX for a plant on an error state; such a plant states its own stage, final and
+    // Q_terms like control/models/Quadrotor_Quat.py:248-275 (USER_HAS_QTERMS: user_gen_stage returns the cost
+    // derivatives on the state and f_x, f_u on the error state, user_gen_qterms is the plant's Q_terms)
+    static constexpr int NX = USER_NX, NU = USER_NU, NDX = USER_NDX, NPAR = USER_NP;
     static constexpr bool HAS_CONTINUOUS = false;
     static constexpr int BACKWARD_WAVES = 1;
 #ifdef USER_WIDE
@@ -105,6 +108,21 @@ struct UserModel {
     static constexpr bool TEAM_BACKWARD = false;
     static constexpr long TAIL_COUNT = 16384;
     static_assert(NX + NU <= 8, "the lane-per-trajectory backward stage keeps every matrix in registers");
+#endif
+#ifdef USER_HAS_QTERMS
+    // what the plant's own stage() returns, and its Q_terms applied to it
+    __device__ static void stage_raw(const double* par, const double* x, const double* u, double* lx, double* lu,
+                                     double* lxx, double* lux, double* luu, double* fx, double* fu)
+    {
+        user_gen_stage(par, x, u, lx, lu, lxx, lux, luu, fx, fu);
+    }
+    __device__ static void q_terms(const double* par, const double* x, const double* lx, const double* lu, const double* lxx,
+                                   const double* lux, const double* luu, const double* fx, const double* fu,
+                                   const double* Vx, const double* V, double* Qx, double* Qu, double* Qxx, double* Qux,
+                                   double* Quu)
+    {
+        user_gen_qterms(par, x, lx, lu, lxx, lux, luu, fx, fu, Vx, V, Qx, Qu, Qxx, Qux, Quu);
+    }
 #endif
     __device__ static void dynamics(const double* par, const double* x, const double* u, double* xn)
     {
@@ -122,10 +140,21 @@ struct UserModel {
         user_gen_cost_final(par, x, &c);
         return c;
     }
+    // (for a plant with its own Q_terms the cost derivatives come back on the error state: its Q_terms at V = 0,
+    // the convention of the quaternion quadrotor)
     __device__ static void stage(const double* par, const double* x, const double* u, double* lx, double* lu,
                                  double* lxx, double* lux, double* luu, double* fx, double* fu)
     {
+#ifdef USER_HAS_QTERMS
+        double rx[NX], rxx[NX * NX], rux[NU * NX], Vx0[NDX], V0[NDX * NDX];
+        for (int i = 0; i < NDX; ++i) Vx0[i] = 0.0;
+        for (int i = 0; i < NDX * NDX; ++i) V0[i] = 0.0;
+        double ru[NU], ruu[NU * NU];
+        user_gen_stage(par, x, u, rx, ru, rxx, rux, ruu, fx, fu);
+        user_gen_qterms(par, x, rx, ru, rxx, rux, ruu, fx, fu, Vx0, V0, lx, lu, lxx, lux, luu);
+#else
         user_gen_stage(par, x, u, lx, lu, lxx, lux, luu, fx, fu);
+#endif
     }
     __device__ static void final(const double* par, const double* x, double* Vx, double* Vxx)
     {
@@ -137,6 +166,7 @@ struct UserModel {
         user_gen_diff_state(par, s, r, dx);      // the plant's own CalcDifferentialState
 #else
         (void)par;
+        static_assert(NDX == NX, "an error state of another dimension needs the plant's own CalcDifferentialState");
         diff_sub<NX>(s, r, dx);
 #endif
     }

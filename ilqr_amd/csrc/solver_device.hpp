@@ -327,6 +327,46 @@ struct CarSparseTerms {
 };
 template <class M> struct TermsOf { using type = DenseTerms<M>; };
 template <> struct TermsOf<CarModel> { using type = CarSparseTerms; };
+#if defined(ILQR_USER_MODEL) && defined(USER_HAS_QTERMS)
+// A user-defined plant with its own Q_terms (control/models/Quadrotor_Quat.py:267-275 is the reference's example):
+// the plant's stage(), then the plant's Q_terms() on what it returned -- the two calls of iLQRController.py:103-104.
+// aux = [fx (n*n), fu (n*m)] on the error state, which is what the regularisation update is made of (:111-113).
+struct UserOwnTerms {
+    using M = UserModel;
+    static constexpr int n = M::NDX, m = M::NU, nx = M::NX, w = n + m;
+    static constexpr int AUX = n * n + n * m;
+    using QP = QPack<n, m>;
+    __device__ static void backward_terms(const double* par, const double* x, const double* u, const double* Vx,
+                                          const double* V, double* Qx, double* Qu, double* QL, double* QU, double* aux)
+    {
+        double lx[nx], lu[m], lxx[nx * nx], lux[m * nx], luu[m * m];
+        double Qxx[n * n], Qux[m * n], Quu[m * m];
+        M::stage_raw(par, x, u, lx, lu, lxx, lux, luu, aux, aux + n * n);
+        M::q_terms(par, x, lx, lu, lxx, lux, luu, aux, aux + n * n, Vx, V, Qx, Qu, Qxx, Qux, Quu);
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                if (i >= j) QL[tri(i, j)] = Qxx[i * n + j];
+                else QU[upp(n, i, j)] = Qxx[i * n + j];
+            }
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+#pragma unroll
+            for (int j = 0; j < n; ++j) QL[tri(n + i, j)] = Qux[i * n + j];
+#pragma unroll
+            for (int j = 0; j < m; ++j) {
+                if (i >= j) QL[tri(n + i, n + j)] = Quu[i * m + j];
+                else QU[upp(m, i, j, QP::UUB)] = Quu[i * m + j];
+            }
+        }
+    }
+    __device__ static void regu_p(const double* aux, double* PL) { DenseTerms<M>::regu_p(aux, PL); }
+    __device__ static void regu_p_exact(const double* aux, double* PL, double* PU) { DenseTerms<M>::regu_p_exact(aux, PL, PU); }
+    __device__ static void final_full(const double* par, const double* x, double* Vx, double* V) { M::final(par, x, Vx, V); }
+};
+template <> struct TermsOf<UserModel> { using type = UserOwnTerms; };
+#endif
 
 // ------------------------------------------------------------------
 // `np.any(np.linalg.eigvals(Q) < 0)` of iLQRController.py:110, decided by an

@@ -36,6 +36,20 @@ way in and cut back on the way out, so the Python interface keeps the plant's
 own dimensions.  A plant that overrides
 CalcDifferentialState (same dimension as the state; e.g. an angle difference
 taken the short way round) has that method traced too.
+
+A plant whose error state has another dimension than its state -- the
+reference's own example is the quaternion quadrotor, control/models/Quadrotor_Quat.py:218-275
+-- declares `ndx` and overrides, like that plant, `CalcDifferentialState`, `stage`, `final` and `Q_terms`.
+All four are traced: they are written with `ilqr_amd.sym` and NumPy's `@` on the arrays handed in, and get their
+raw derivatives from `self.derivatives(x, u)` / `self.final_derivatives(x)` (symbolic when x is, numbers otherwise):
+
+    def stage(self, x, u):
+        l_x, l_u, l_xx, l_ux, l_uu, A, B = self.derivatives(x, u)
+        G = self.G(x)                                        # the plant's own nx x ndx map
+        return l_x, l_u, l_xx, l_ux, l_uu, G.T @ A @ G, G.T @ B
+    def Q_terms(self, x, l_x, l_u, l_xx, l_ux, l_uu, f_x, f_u, V_x, V_xx): ...   # as Quadrotor_Quat.py:267-275
+
+(one trajectory per lane: nx + nu <= 8).
 """
 from __future__ import annotations
 
@@ -51,9 +65,9 @@ from .model import Model
 class UserModel(Model):
     _model_id = _lib.MODEL_USER
 
-    def __init__(self, nx: int, nu: int, params=None, name: str | None = None):
+    def __init__(self, nx: int, nu: int, params=None, name: str | None = None, ndx: int | None = None):
         super().__init__()
-        self.nx, self.nu, self.ndx = int(nx), int(nu), int(nx)
+        self.nx, self.nu, self.ndx = int(nx), int(nu), int(nx if ndx is None else ndx)
         self.p = np.array([] if params is None else params, dtype=np.float64).ravel()
         self.name = name or type(self).__name__.lower()
         self._library = None
@@ -65,6 +79,16 @@ class UserModel(Model):
         # the plant's own CalcDifferentialState (model.py:22-23 overridden), traced like the other three
         self._user_diff = (cls.CalcDifferentialState
                            if cls.CalcDifferentialState is not UserModel.CalcDifferentialState else None)
+        # the plant's own stage / final / Q_terms (Quadrotor_Quat.py:248-275): all three or none
+        own = {k: getattr(cls, k) for k in ("stage", "final", "Q_terms") if getattr(cls, k) is not getattr(UserModel, k)}
+        if own and len(own) != 3:
+            raise TypeError(f"{cls.__name__} overrides {sorted(own)}: a plant that states its own Q-function terms "
+                            "overrides stage, final and Q_terms together (Quadrotor_Quat.py:248-275)")
+        if self.ndx != self.nx and (not own or self._user_diff is None):
+            raise TypeError(f"{cls.__name__}: ndx = {self.ndx} != nx = {self.nx} needs the plant's own "
+                            "CalcDifferentialState, stage, final and Q_terms (Quadrotor_Quat.py:218-275)")
+        self._user_own = own or None
+        self._sym_cache = None
 
     # ------------------------------------------------------------ the user's own Python
     def python_dynamics(self, x, u):
@@ -76,6 +100,53 @@ class UserModel(Model):
 
     def python_cost_final(self, x):
         return float(self._user[2](self, np.asarray(x, dtype=np.float64)))
+
+    # ------------------------------------------------------------ raw derivatives for the plant's own stage / final
+    def _sym(self):
+        """SymPy expressions of the three functions and their derivatives (in x, u, p symbols), built once."""
+        if self._sym_cache is None:
+            import sympy as sp
+            from .. import codegen
+            xs, us, ps, f, l, lf = codegen.user_expressions(self.nx, self.nu, self.p.shape[-1], self._traced(0),
+                                                            self._traced(1), self._traced(2))[:6]
+            lx = sp.Matrix([l]).jacobian(xs); lu = sp.Matrix([l]).jacobian(us); lfx = sp.Matrix([lf]).jacobian(xs)
+            ex = dict(l_x=lx.T, l_u=lu.T, l_xx=lx.jacobian(xs), l_ux=lu.jacobian(xs), l_uu=lu.jacobian(us),
+                      f_x=f.jacobian(xs), f_u=f.jacobian(us), lf_x=lfx.T, lf_xx=lfx.jacobian(xs))
+            self._sym_cache = dict(xs=xs, us=us, ps=ps, ex=ex, fn={})
+        return self._sym_cache
+
+    def _derivs(self, keys, x, u):
+        import sympy as sp
+        c = self._sym()
+        x = np.asarray(x)
+        symbolic = x.dtype == object or (u is not None and np.asarray(u).dtype == object)
+        p = np.asarray(self.p)
+        out = []
+        for k in keys:
+            M = c["ex"][k]
+            if symbolic:
+                sub = dict(zip(c["xs"], x))
+                if u is not None:
+                    sub.update(zip(c["us"], np.asarray(u)))
+                sub.update(zip(c["ps"], p.ravel()[:len(c["ps"])]) if p.size else [])
+                a = np.array(M.xreplace(sub).tolist(), dtype=object)
+            else:
+                if k not in c["fn"]:
+                    c["fn"][k] = sp.lambdify(list(c["xs"]) + list(c["us"]) + list(c["ps"]), M, "numpy")
+                uu = np.zeros(self.nu) if u is None else np.asarray(u, dtype=np.float64)
+                pp = p.ravel() if p.size else np.zeros(1)
+                a = np.asarray(c["fn"][k](*np.asarray(x, dtype=np.float64), *uu, *pp[:len(c["ps"])]), dtype=np.float64)
+            out.append(a.ravel() if a.shape[1] == 1 else a)
+        return out
+
+    def derivatives(self, x, u):
+        """(l_x, l_u, l_xx, l_ux, l_uu, A, B) of the three functions the plant wrote, on the STATE (nx), for the
+        plant's own stage(): SymPy entries when x or u hold symbols (tracing), numbers otherwise."""
+        return tuple(self._derivs(("l_x", "l_u", "l_xx", "l_ux", "l_uu", "f_x", "f_u"), x, u))
+
+    def final_derivatives(self, x):
+        """(l_final_x, l_final_xx) on the state, for the plant's own final()."""
+        return tuple(self._derivs(("lf_x", "lf_xx"), x, None))
 
     # ------------------------------------------------------------ tracing and building
     def _traced(self, which):
@@ -103,8 +174,22 @@ class UserModel(Model):
                     return self._user_diff(self, s, r)
                 finally:
                     self.p = saved
+        overrides = None
+        if self._user_own:
+            def with_p(fn):
+                def call(*args):
+                    *a, p = args
+                    saved = self.p
+                    self.p = p
+                    try:
+                        return fn(self, *a)
+                    finally:
+                        self.p = saved
+                return call
+            overrides = dict(stage=with_p(self._user_own["stage"]), final=with_p(self._user_own["final"]),
+                             q_terms=with_p(self._user_own["Q_terms"]))
         return codegen.user_expressions(self.nx, self.nu, self.p.shape[-1], self._traced(0), self._traced(1),
-                                        self._traced(2), diff)
+                                        self._traced(2), diff, ndx=self.ndx, overrides=overrides)
 
     def header_text(self) -> str:
         from .. import codegen
@@ -133,8 +218,10 @@ class UserModel(Model):
         return self
 
     def _bind(self):
-        # from here on the Model interface evaluates the compiled code
-        for meth in ("discrete_dynamics", "_cost_stage", "_cost_final"):
+        # from here on the Model interface evaluates the compiled code (stage / final of a plant that states its own
+        # Q-function terms come back as the library has them: cost derivatives already on the error state, i.e. the
+        # plant's Q_terms at V = 0, the convention of the quaternion quadrotor in include/ilqr_hip.h)
+        for meth in ("discrete_dynamics", "_cost_stage", "_cost_final") + (("stage", "final") if self._user_own else ()):
             setattr(self, meth, types.MethodType(getattr(Model, meth), self))
 
     # ------------------------------------------------------------ plants the library states wider than written

@@ -441,14 +441,31 @@ static void user_diff(const double *par, const double *s, const double *r, doubl
 #else
 DEF_DIFF_SUB(user_diff, USER_NX)
 #endif
+#ifdef USER_HAS_QTERMS
+/* the plant's own Q_terms (control/models/Quadrotor_Quat.py:267-275 is the reference's example), as traced */
+static void user_q_terms(const ilqr_oracle_model *M, const double *par, const double *x, const double *lx,
+                         const double *lu, const double *lxx, const double *lux, const double *luu, const double *fx,
+                         const double *fu, const double *Vx, const double *Vxx, double *Qx, double *Qu, double *Qxx,
+                         double *Qux, double *Quu)
+{
+    (void)M;
+    user_gen_qterms(par, x, lx, lu, lxx, lux, luu, fx, fu, Vx, Vxx, Qx, Qu, Qxx, Qux, Quu);
+}
+#define USER_Q_TERMS user_q_terms
+#else
+#define USER_Q_TERMS q_terms_default_export
+#endif
+#ifndef USER_NDX
+#define USER_NDX USER_NX
+#endif
 #endif
 
 static const ilqr_oracle_model *oracle_model_table(int id)
 {
 #ifdef ORACLE_USER_MODEL
-    static const ilqr_oracle_model U = {USER_NX, USER_NU, USER_NX, USER_NP, user_dynamics, user_cost_stage,
+    static const ilqr_oracle_model U = {USER_NX, USER_NU, USER_NDX, USER_NP, user_dynamics, user_cost_stage,
                                         user_cost_final, user_gen_stage, user_gen_final, user_diff,
-                                        q_terms_default_export};
+                                        USER_Q_TERMS};
     if (id == 4) return &U;
 #endif
     static const ilqr_oracle_model T[4] = {

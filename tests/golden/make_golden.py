@@ -85,7 +85,7 @@ def make_user_plant(spec):
 
     class Plant(Model):
         def __init__(self):
-            self.nx, self.nu, self.ndx = n, m, n
+            self.nx, self.nu, self.ndx = n, m, um.ndx
             self.p = um.p
 
         def discrete_dynamics(self, x, u):
@@ -113,6 +113,13 @@ def make_user_plant(spec):
             return (np.asarray(fn["lf_x"](*x), dtype=np.float64).reshape(n),
                     np.asarray(fn["lf_xx"](*x), dtype=np.float64).reshape(n, n))
 
+    if um._user_own:
+        # the plant's own stage / final / Q_terms, run as written on NumPy arrays by the reference solver
+        # (the overrides of control/models/Quadrotor_Quat.py:248-275)
+        f64 = lambda t: tuple(np.asarray(a, dtype=np.float64) for a in t)
+        Plant.stage = lambda self, x, u: f64(um._user_own["stage"](um, np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64)))
+        Plant.final = lambda self, x: f64(um._user_own["final"](um, np.asarray(x, dtype=np.float64)))
+        Plant.Q_terms = lambda self, x, *a: f64(um._user_own["Q_terms"](um, np.asarray(x, dtype=np.float64), *a))
     return Plant()
 
 
@@ -585,6 +592,15 @@ def gen_user_compass(pool):
     run_cases("user_compass", dict(model="user", cls="Compass"), COMPASS_SP, x0, u0, pool)
 
 
+def gen_user_skiff(pool):
+    """A plant defined by the user on an error state of another dimension than its state, with its own
+    CalcDifferentialState, stage, final and Q_terms (tests/user_models.py Skiff)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from user_models import SKIFF_SP, skiff_inputs
+    x0, u0 = skiff_inputs(32, 21)
+    run_cases("user_skiff", dict(model="user", cls="Skiff"), SKIFF_SP, x0, u0, pool)
+
+
 def gen_quat_utils(pool):
     """Outputs of the reference's NumPy quaternion helpers (maths/quaternions.py) on random quaternions."""
     from maths import quaternions as rq
@@ -601,7 +617,7 @@ def gen_quat_utils(pool):
     print("[golden] quat_utils: 32 quaternions", flush=True)
 
 
-GENS = dict(quat_utils=gen_quat_utils, user_rover=gen_user_rover, user_tug=gen_user_tug, user_compass=gen_user_compass, car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
+GENS = dict(quat_utils=gen_quat_utils, user_rover=gen_user_rover, user_tug=gen_user_tug, user_compass=gen_user_compass, user_skiff=gen_user_skiff, car_readme=gen_car_readme, car_mpc=gen_car_mpc, car_box=gen_car_box, car_adv=gen_car_adversarial,
             acrobot=gen_acrobot, quad_ea=gen_quad_ea, quad_quat=gen_quad_quat, baseline=gen_baseline_horizons, variants=gen_variants, near_goal=gen_near_goal, units=gen_units)
 
 

@@ -15,7 +15,7 @@ import pytest
 
 from conftest import ROOT, load_golden
 from helpers import compare_to_golden, rel_traj
-from user_models import COMPASS_SP, ROVER_SP, TUG_SP, Compass, Rover, Tug, compass_inputs, rover_inputs, tug_inputs
+from user_models import COMPASS_SP, ROVER_SP, SKIFF_SP, TUG_SP, Compass, Rover, Skiff, Tug, compass_inputs, rover_inputs, skiff_inputs, tug_inputs
 
 
 @pytest.fixture(scope="module")
@@ -177,8 +177,62 @@ def test_overridden_differential_state_is_traced_and_matters(oracle, tmp_path_fa
         def CalcDifferentialState(self, state, ref_state):
             return state[:2] - ref_state[:2]
 
-    with pytest.raises(NotImplementedError, match="Q_terms"):
+    with pytest.raises(TypeError, match="Q_terms"):        # another dimension needs the plant's own Q_terms as well
+        class Shorter2(Compass):
+            def __init__(self):
+                UserModel_init(self, nx=3, nu=2, ndx=2, params=[-2.0, 0.5], name="shorter")
+
+            def CalcDifferentialState(self, state, ref_state):
+                return state[:2] - ref_state[:2]
+        Shorter2()
+    with pytest.raises(ValueError, match="ndx"):
         Shorter().trace()
+
+
+def UserModel_init(self, **kw):
+    from ilqr_amd.models.user import UserModel
+    UserModel.__init__(self, **kw)
+
+
+def test_error_state_plant_with_its_own_q_terms(oracle, tmp_path_factory):
+    """A plant on an error state of another dimension than its state, with its own CalcDifferentialState, stage, final
+    and Q_terms -- what control/models/Quadrotor_Quat.py:218-275 is in the reference.  The reference's iLQR ran the
+    plant as written (its overrides executing on NumPy arrays; tests/golden/user_skiff.npz: 32 solves, all regularised,
+    29 with backtracking); the four methods are traced and printed, and the checker compiled with that header
+    reproduces the reference's decisions, costs and trajectories."""
+    g = load_golden("user_skiff")
+    plant = Skiff()
+    assert plant.get_dims() == (5, 2, 4)
+    text = plant.header_text()
+    for tok in ("#define USER_NDX 4", "#define USER_HAS_QTERMS 1", "#define USER_HAS_DIFF 1", "user_gen_qterms"):
+        assert tok in text, tok
+    d = tmp_path_factory.mktemp("skiff_hdr")
+    (d / "user_gen.h").write_text(text)
+    chk = oracle.build_user(str(d), out_dir=str(d))
+    assert oracle.dims("user", library=chk)[:3] == (5, 2, 4)
+    r = oracle.solve_batch("user", g["par"], int(g["N"]), int(g["max_iter"]), int(g["max_ls"]), float(g["d_tol"]), g["x0"],
+                           g["u_init"], library=chk)
+    i = r["info"]
+    assert (g["regu_rounds"] > 0).all() and (g["ls_evals"] > 1).any(axis=1).sum() >= 20
+    n = compare_to_golden(g, r["x"], r["u"], i["J_last"], i["iters"], i["status"], i["ls_evals"], i["accepted"],
+                          i["regu_rounds"], J0=i["J0"], label="user_skiff")
+    assert n >= 26 and n.within_1e8 >= 22
+    # the raw derivatives the plant's own stage() is written with, against finite differences of its Python
+    x, u = g["x0"][3], g["u_init"][3, 0]
+    l_x, l_u, l_xx, l_ux, l_uu, A, B = plant.derivatives(x, u)
+    h = 1e-6
+    for k in range(5):
+        e = np.zeros(5); e[k] = h
+        fd = (plant.python_dynamics(x + e, u) - plant.python_dynamics(x - e, u)) / (2 * h)
+        assert np.allclose(A[:, k], fd, rtol=1e-6, atol=1e-8), k
+        fd = (plant.python_cost_stage(x + e, u) - plant.python_cost_stage(x - e, u)) / (2 * h)
+        assert abs(l_x[k] - fd) < 1e-6 * max(1.0, abs(fd)), k
+    # only one trajectory per lane: a wide plant with its own Q_terms is refused with the reason
+    class WideSkiff(Skiff):
+        def __init__(self):
+            UserModel_init(self, nx=9, nu=2, ndx=8, params=[0.0] * 6, name="wideskiff")
+    with pytest.raises((NotImplementedError, ValueError)):
+        WideSkiff().trace()
 
 
 # ----------------------------------------------------------------------------------------------- GPU
@@ -344,6 +398,41 @@ def test_wide_user_plant_batch_and_model_interface_on_gpu(oracle, tug_gpu):
         infos, xs_, us_ = _solve(tug_gpu, TUG_SP, x0[idx], u0[idx])
         assert np.array_equal(xs_, xm[idx], equal_nan=True) and np.array_equal(us_, um[idx], equal_nan=True), k
         assert np.array_equal(infos.iters.cpu().numpy(), infom.iters.cpu().numpy()[idx])
+
+
+@pytest.mark.gpu
+def test_error_state_plant_on_gpu_matches_reference_golden(oracle):
+    """The Skiff (own CalcDifferentialState, stage, final, Q_terms; nx = 5, error state 4) solved by the kernels,
+    against the reference's solve of the plant as written, under both eigenvalue rules; the Model interface returns the
+    cost derivatives on the error state (the plant's Q_terms at V = 0)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ilqr_amd.iLQRController import iLQR
+    plant = Skiff()
+    plant.use_library(os.path.join(plant.library_dir(), "libilqr_user.so"))
+    g = load_golden("user_skiff")
+    plant.set_params(g["par"])
+    for eig in ("ldl", "lapack"):
+        ctl = iLQR(plant, int(g["N"]), int(g["max_iter"]), int(g["max_ls"]), float(g["d_tol"]), trace_len=64, eigvals=eig)
+        x, u = ctl.run_ilqr(np.array(g["x0"]), np.array(g["u_init"], copy=True))
+        info, t = ctl.info, ctl.info.traces
+        assert x.shape == (32, 50, 5) and u.shape == (32, 49, 2)
+        n = compare_to_golden(g, x, u, info.J.cpu().numpy(), info.iters.cpu().numpy(), info.status.cpu().numpy(),
+                              t["ls_evals"].cpu().numpy(), t["accepted"].cpu().numpy(), info.regu_rounds.cpu().numpy(),
+                              J0=info.J0.cpu().numpy(), label="user_skiff (%s)" % eig)
+        assert n >= 26 and n.within_1e8 >= 22, (eig, n, n.within_1e8)
+    xs, us = g["x0"][5], g["u_init"][5, 0]
+    assert np.allclose(plant.discrete_dynamics(xs, us), plant.python_dynamics(xs, us), rtol=1e-13, atol=1e-15)
+    l_x, l_u, l_xx, l_ux, l_uu, f_x, f_u = plant.stage(xs, us)
+    raw = Skiff.stage(Skiff(), xs, us)             # the plant's own Python
+    G = np.asarray(Skiff().G(xs), dtype=np.float64)
+    assert l_x.shape == (4,) and l_xx.shape == (4, 4) and f_x.shape == (4, 4) and f_u.shape == (4, 2)
+    assert np.allclose(l_x, G.T @ raw[0], rtol=1e-11, atol=1e-12) and np.allclose(l_xx, G.T @ raw[2] @ G, rtol=1e-11, atol=1e-11)
+    assert np.allclose(f_x, raw[5], rtol=1e-11, atol=1e-12) and np.allclose(f_u, raw[6], rtol=1e-11, atol=1e-12)
+    V_x, V_xx = plant.final(xs)
+    rawf = Skiff.final(Skiff(), xs)
+    assert np.allclose(V_x, rawf[0], rtol=1e-11, atol=1e-12) and np.allclose(V_xx, rawf[1], rtol=1e-11, atol=1e-11)
 
 
 @pytest.mark.gpu

@@ -130,3 +130,87 @@ def compass_inputs(B, seed):
     u0 = np.column_stack([np.full(B, 1.0), rng.choice([-1.0, 1.0], B) * 1.5])[:, None, :] * np.ones((1, COMPASS_SP["N"] - 1, 1)) \
         + 0.1 * rng.standard_normal((B, COMPASS_SP["N"] - 1, 2))
     return x0, u0
+
+
+class Skiff(UserModel):
+    """A planar vehicle whose heading is a unit complex number (c, s) instead of an angle -- the 2-D relative of the
+    reference's quaternion quadrotor (control/models/Quadrotor_Quat.py): the state has five components, the error
+    state four, and the plant states its own CalcDifferentialState, stage, final and Q_terms through the map G(x)
+    from error state to state, as Quadrotor_Quat.py:218-275 does.
+
+    x = [px, py, c, s, speed], u = [acceleration, turn rate], error state [dpx, dpy, dheading, dspeed],
+    p = [goal_x, goal_y, goal_c, goal_s, obstacle_x, obstacle_y].  (c, s) is normalised wherever it is used, like the
+    quaternion in maths/casadi_quaternions.py:8.
+    """
+    DT = 0.1
+    Q = np.diag([1.0, 1.0, 0.5, 0.1])
+    QF = np.diag([60.0, 60.0, 20.0, 5.0])
+
+    def __init__(self, goal=(2.5, 1.0, 1.0, 0.0), obstacle=(1.2, 0.3)):
+        super().__init__(nx=5, nu=2, ndx=4, params=[*goal, *obstacle], name="skiff")
+
+    @staticmethod
+    def _heading(x):
+        n = m.sqrt(x[2] * x[2] + x[3] * x[3])
+        return x[2] / n, x[3] / n
+
+    def G(self, x):
+        """d state / d error state, 5 x 4: the heading moves along the tangent (-s, c) of the unit circle."""
+        c, s = self._heading(x)
+        return m.array([1.0, 0.0, 0.0, 0.0,
+                        0.0, 1.0, 0.0, 0.0,
+                        0.0, 0.0, -s, 0.0,
+                        0.0, 0.0, c, 0.0,
+                        0.0, 0.0, 0.0, 1.0]).reshape(5, 4)
+
+    def discrete_dynamics(self, x, u):
+        h = self.DT
+        c, s = self._heading(x)
+        cw, sw = m.cos(h * u[1]), m.sin(h * u[1])
+        return m.array([x[0] + h * x[4] * c, x[1] + h * x[4] * s, c * cw - s * sw, s * cw + c * sw, x[4] + h * u[0]])
+
+    def _error(self, x):
+        ref = m.array([self.p[0], self.p[1], self.p[2], self.p[3], 0.0 * self.p[0]])
+        return self.G(x).T @ (x - ref)
+
+    def _bump(self, x):
+        d2 = (x[0] - self.p[4]) ** 2 + (x[1] - self.p[5]) ** 2
+        return 3.0 * m.exp(-d2 / 0.2)
+
+    def _cost_stage(self, x, u):
+        e = self._error(x)
+        return 0.5 * (e @ (self.Q @ e)) + self._bump(x) + 0.5 * (0.2 * u[0] ** 2 + 0.1 * u[1] ** 2)
+
+    def _cost_final(self, x):
+        e = self._error(x)
+        return 0.5 * (e @ (self.QF @ e))
+
+    # ---- the overrides of Quadrotor_Quat.py:218-275
+    def CalcDifferentialState(self, state, ref_state):
+        return self.G(state).T @ (state - ref_state)
+
+    def stage(self, x, u):
+        l_x, l_u, l_xx, l_ux, l_uu, A, B = self.derivatives(x, u)
+        G = self.G(x)
+        return l_x, l_u, l_xx, l_ux, l_uu, G.T @ A @ G, G.T @ B
+
+    def final(self, x):
+        lf_x, lf_xx = self.final_derivatives(x)
+        G = self.G(x)
+        return G.T @ lf_x, G.T @ lf_xx @ G
+
+    def Q_terms(self, x, l_x, l_u, l_xx, l_ux, l_uu, f_x, f_u, V_x, V_xx):
+        G = self.G(x)
+        return (G.T @ l_x + f_x.T @ V_x, l_u + f_u.T @ V_x, G.T @ l_xx @ G + f_x.T @ V_xx @ f_x,
+                l_ux @ G + f_u.T @ V_xx @ f_x, l_uu + f_u.T @ V_xx @ f_u)
+
+
+SKIFF_SP = dict(N=50, max_iter=50, max_ls=20, d_tol=1e-3)
+
+
+def skiff_inputs(B, seed):
+    rng = np.random.default_rng(seed)
+    th = rng.uniform(-np.pi, np.pi, B)
+    x0 = np.column_stack([rng.uniform(-1, 1, B), rng.uniform(-1, 1, B), np.cos(th), np.sin(th), rng.uniform(0, 1.0, B)])
+    u0 = 0.3 * rng.standard_normal((B, SKIFF_SP["N"] - 1, 2))
+    return x0, u0
