@@ -22,4 +22,13 @@ extern "C" int ilqr_debug_counters(unsigned long long* out16, int reset)
     }
     return 0;
 }
+extern "C" int ilqr_debug_histograms(unsigned long long* out32, int reset)
+{
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(ilqr::g_hist), sizeof(ilqr::g_hist)) != hipSuccess) return -3;
+    if (reset) {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ilqr::g_hist), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
 #endif

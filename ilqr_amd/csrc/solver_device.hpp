@@ -517,6 +517,11 @@ struct PackedFull {
 // build-time diagnostics (tools/debug_counters.py): [2 site] calls of exact_negative by a wavefront, [2 site + 1] those
 // in which some lane took LAPACK's path; sites 0 round 0, 1 group scan, 2 stuck scan; [8] lanes in doubt, summed
 static __device__ unsigned long long g_dbg[16];
+// [0][b]: trajectory-passes of the second launch by 64-round trips of their own scans (bin b: 2^(b-1) < trips <= 2^b,
+// bin 0: none); [1][b]: the same per wavefront-pass (trips of all its trajectories)
+static __device__ unsigned long long g_hist[2][16];
+static __device__ int g_trips_lane;      // (unused placeholder so that the symbol list stays stable)
+__device__ __forceinline__ int dbg_bin(int t) { int b = 0; while ((1 << b) < t + 1 && b < 15) ++b; return b; }
 #define ILQR_DBG_SITE(k) , (k)
 #else
 #define ILQR_DBG_SITE(k)
@@ -616,7 +621,11 @@ __device__ __forceinline__ double running_sum(double v, double p, int k0, int co
 template <class M, bool EXACT = false, bool DEFER = false>
 __device__ __forceinline__ bool backward_stage(const double* par, double* xu, const double* next, double* Vx, double* V,
                                       double* dk, double* Kk, double& redu, int& regu_rounds, int& regu_stages,
-                                      double& maxq, bool alive, double* lds, bool& dirty, bool& deferred)
+                                      double& maxq, bool alive, double* lds, bool& dirty, bool& deferred
+#ifdef ILQR_DEBUG_COUNTERS
+                                      , int& dbg_trips
+#endif
+)
 {
     const double* const xk = xu;
     const double* const uk = xu + M::NX;
@@ -823,6 +832,9 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
             }
             for (int base = REGU_BASE + 1;; base += 64) {
                 wave_sync();
+#ifdef ILQR_DEBUG_COUNTERS
+                if (lane == src) dbg_trips += 1;
+#endif
                 double mq = 0.0;
                 int t;
                 {
@@ -1111,6 +1123,9 @@ __device__ __forceinline__ bool backward_pass(const double* par, const RecIn& T,
                                      double& dmax, int& regu_rounds, int& regu_stages, double& maxq, bool active,
                                      double* lds, bool& dirty, bool& deferred)
 {
+#ifdef ILQR_DEBUG_COUNTERS
+    int dbg_trips = 0;
+#endif
     using TR = typename TermsOf<M>::type;
     constexpr int n = M::NDX, m = M::NU, nx = M::NX;
     double Vx[n], V[n * n], xu[nx + m], g[m + m * n];
@@ -1128,7 +1143,11 @@ __device__ __forceinline__ bool backward_pass(const double* par, const RecIn& T,
         const bool alive = active && ok && !deferred;
         // (the stage leaves the record of stage k - 1 in xu; the last one loads its own again)
         const bool good = backward_stage<M, EXACT, DEFER>(par, xu, T.p + (long)(k > 0 ? k - 1 : 0) * T.ss, Vx, V, dk, Kk, redu,
-                                            regu_rounds, regu_stages, maxq, alive, lds, dirty, deferred);
+                                            regu_rounds, regu_stages, maxq, alive, lds, dirty, deferred
+#ifdef ILQR_DEBUG_COUNTERS
+                                            , dbg_trips
+#endif
+        );
         ok = ok && good;
         // stored by every lane, whatever its state (a lane without a trajectory is given a scratch record by
         // the caller, a failed one writes gains nobody reads): a fixed number of stores, all younger than the
@@ -1144,6 +1163,14 @@ __device__ __forceinline__ bool backward_pass(const double* par, const RecIn& T,
     }
     deltaJ = redu;
     dmax = anynan ? NAN : best;
+#ifdef ILQR_DEBUG_COUNTERS
+    if (EXACT && !DEFER) {
+        if (active) atomicAdd(&g_hist[0][dbg_bin(dbg_trips)], 1ull);
+        int tot = dbg_trips;
+        for (int d = 32; d >= 1; d /= 2) tot += __shfl_xor(tot, d);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_hist[1][dbg_bin(tot)], 1ull);
+    }
+#endif
     return ok;
 }
 

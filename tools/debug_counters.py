@@ -22,6 +22,8 @@ s = BatchSolver(0, [2.0, 2.0], 40, max_iter, 20, 1e-3, device=dev, flags=_lib.FL
 x0, u0 = bench.car_inputs(B, 1234)
 L = s.lib
 out = (C.c_ulonglong * 16)()
+hist = (C.c_ulonglong * 32)()
+L.ilqr_debug_histograms(hist, 1)
 L.ilqr_debug_counters(out, 1)
 r = s.solve(x0, u0)
 torch.cuda.synchronize()
@@ -30,6 +32,10 @@ v = list(out)
 for k, name in enumerate(("round 0", "group scan", "stuck scan")):
     print(f"{name:11s}: wavefront calls {v[2 * k]:10d}, with LAPACK {v[2 * k + 1]:10d} ({v[2 * k + 1] / max(v[2 * k], 1):.3f}), "
           f"lanes in doubt per call {v[8 + k] / max(v[2 * k], 1):.2f}")
+L.ilqr_debug_histograms(hist, 1)
+h = list(hist)
+print("second launches, 64-round trips per trajectory-pass, bins 0, 1, 2, <=4, <=8, ...:", h[:14])
+print("second launches, trips per wavefront-pass,           bins 0, 1, 2, <=4, <=8, ...:", h[16:30])
 trips = max(v[4], 1)
 print(f"stuck scans: {v[12] / 1e6:.1f} Mcycles in total, {v[12] / trips:.0f} cycles per 64-round trip")
 print(f"passes of wavefronts: first launches {v[6]} passes, {v[13] / max(v[6], 1):.0f} cycles each; second launches {v[7]} passes, "
