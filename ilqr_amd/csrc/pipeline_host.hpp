@@ -113,7 +113,7 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
         iters_run = iter;
         a.count = (int)count;
         a.iter = iter;
-        a.s_first = 0; a.s_step = 1; a.group = (int)(count - back); a.lanes = PIPE_WG;
+        a.s_first = 0; a.s_step = 1; a.group = (int)(count - back); a.lanes = PIPE_WG; a.n_range = a.group; a.spread = 0;
         // Latency-bound regime (about one wavefront per SIMD or less): fewer, wider launches per iteration.
         // The schedule does not change any result, so neither does the threshold.
         const bool tail = count <= TAIL_COUNT && a.max_ls >= 2 &&
@@ -134,29 +134,41 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
                                    dim3(PIPE_WG), 0, st, a);
             }
         } else if (a.flags & ILQR_FLAG_LAPACK_EIGVALS) {
-            // First the trajectories whose tests have been cheap so far, 64 per wavefront; one that turns out to need a
-            // long scan is dropped by that launch and listed.  Then those that needed one before (slots from the back)
-            // and the listed ones, spread thinly: as few per wavefront as still gives every SIMD its wavefronts (three
-            // workgroups of this kernel fit a CU), because the long scans of one wavefront's trajectories run one
-            // after the other and the launch takes as long as its slowest wavefront.  Results do not depend on it.
-            long n_defer = 0;
-            if (a.group > 0) {
+            // Three launches (Pipe::s_first).  The first two drop and list a trajectory at the stage where it turns out
+            // to need a long scan; the third runs the listed ones again from their last stage, few per wavefront.
+            // The back and the list are spread thinly: as few per wavefront as still gives every SIMD its wavefronts
+            // (three workgroups of this kernel fit a CU).  Results do not depend on any of it.
+            long resident = 768 / (a.parts > 0 ? a.parts : 1);
+            if (const char* e = getenv("ILQR_HIP_DIRTY_WAVES")) resident = atol(e);     // for tuning
+            if (a.group > 0)
                 hipLaunchKernelGGL((pipe_backward_kernel<M, PT, true, true>), dim3(blocks_for(a.group, PIPE_WG)), dim3(PIPE_WG), 0,
                                    st, a);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(h, a.cnt + CNT_DEFER, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                n_defer = h[0];
-            }
-            if (back + n_defer > 0) {
+            if (back > 0) {
                 Pipe b = a;
-                b.s_first = (int)a.B - 1; b.s_step = -1; b.group = (int)(back + n_defer); b.n_back = (int)back;
-                long resident = 768 / (a.parts > 0 ? a.parts : 1);
-                if (const char* e = getenv("ILQR_HIP_DIRTY_WAVES")) resident = atol(e);     // for tuning
+                b.s_first = (int)a.B - 1; b.s_step = -1; b.group = (int)back; b.n_range = (int)back; b.spread = 1;
                 long most = 16;
                 if (const char* e = getenv("ILQR_HIP_DIRTY_LANES")) most = atol(e);        // for tuning
                 int lanes = 1;
                 while (lanes < most && (long)blocks_for(b.group, 2 * lanes) >= resident) lanes *= 2;
+                b.lanes = lanes;
+                hipLaunchKernelGGL((pipe_backward_kernel<M, PT, true, true>), dim3(blocks_for(b.group, lanes)), dim3(PIPE_WG), 0,
+                                   st, b);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h, a.cnt + CNT_DEFER, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const long n_defer = h[0];
+            if (n_defer > 0) {
+                Pipe b = a;
+                b.group = (int)n_defer; b.n_range = 0; b.spread = 1;
+                // (the kernel of this launch keeps less in LDS: four of its workgroups fit a CU, and up to WIDE_TRAJ
+                // trajectories of a wavefront share each test of 64 matrices)
+                long most = WIDE_TRAJ, fill = 1024 / (a.parts > 0 ? a.parts : 1);
+                if (const char* e = getenv("ILQR_HIP_HEAVY_LANES")) most = atol(e);        // for tuning
+                if (const char* e = getenv("ILQR_HIP_HEAVY_FILL")) fill = atol(e);         // for tuning
+                if (most > WIDE_TRAJ) most = WIDE_TRAJ;
+                int lanes = 1;
+                while (lanes < most && (long)blocks_for(b.group, 2 * lanes) >= fill) lanes *= 2;
                 b.lanes = lanes;
                 hipLaunchKernelGGL((pipe_backward_kernel<M, PT, true, false>), dim3(blocks_for(b.group, lanes)), dim3(PIPE_WG), 0,
                                    st, b);

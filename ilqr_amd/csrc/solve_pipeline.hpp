@@ -91,15 +91,17 @@ struct Pipe {
     int32_t* cnt;              // [0] slots handed out in B, [1] line-search entries, [2] rejected at alpha = 1,
                                // [3..] list lengths of the later stages
     int count;                 // running trajectories = used slots of buffer A
-    // The slots one backward launch covers: s_first, s_first + s_step, ... (`group` of them), `lanes` per wavefront.
-    // Slots are handed out from both ends of the buffer: trajectories whose tests the certified screen has settled
-    // so far from the front, the others ("dirty": they run LAPACK's path at most stages) from the back, so that a
-    // wavefront holds one kind.  Wavefronts of the second kind are launched with fewer trajectories each when
-    // there are few of them: what such a launch takes is the longest chain of LAPACK tests in one wavefront.
-    int s_first, s_step, group, lanes;
-    // The launch for the second kind covers `n_back` slots counted down from s_first and then the slots listed in
-    // `defer`: trajectories that the first launch of this iteration dropped when they needed a long scan.
-    int n_back;
+    // The slots one backward launch covers, `group` of them, `lanes` per wavefront: entry i < n_range is slot
+    // s_first + i * s_step, the entries after those are the slots listed in `defer`.
+    // With ILQR_FLAG_LAPACK_EIGVALS slots are handed out from both ends of the buffer: trajectories whose tests the
+    // certified screen has settled so far from the front, the others ("dirty": they run LAPACK's path at most
+    // stages) from the back, so that a wavefront holds one kind, and an iteration's backward pass is three launches:
+    // the front, 64 per wavefront; the back, fewer per wavefront; and, one or two per wavefront, the trajectories
+    // those two dropped and listed in `defer` because they needed a long regularisation scan (such scans run one
+    // after the other in a wavefront, and a launch takes as long as its slowest wavefront).
+    int s_first, s_step, group, lanes, n_range;
+    int spread;                // entry of lane l of wavefront b: l * wavefronts + b instead of b * lanes + l, so that
+                               // neighbours in a list, which tend to be alike in how long they take, meet in no wavefront
     int32_t* defer;
     int tail;                  // few trajectories left: every search is evaluated side by side from its first candidate
     int iter;                  // 1-based number of the iteration being run
@@ -239,14 +241,12 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_export_kernel(Pipe a)
 template <class M, bool PT = false, bool EXACT = false, bool DEFER = false>
 __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kernel(Pipe a)
 {
-    __shared__ double lds[stage_lds_doubles<M::NDX, M::NU, TermsOf<M>::type::AUX>() +
+    __shared__ double lds[stage_lds_doubles<M::NDX, M::NU, TermsOf<M>::type::AUX, (EXACT && !DEFER) ? WIDE_PARK : 64>() +
                           (EXACT ? exact_lds_doubles<M::NDX, M::NU>() : 0)];
-    // (second kind: lane l of wavefront b takes entry l * wavefronts + b, so that neighbours in the list, which
-    // tend to be alike in how long their scans take, end up in different wavefronts)
-    const int i0 = (EXACT && !DEFER) ? (int)(threadIdx.x * gridDim.x + blockIdx.x) : (int)(blockIdx.x * a.lanes + threadIdx.x);
+    const int i0 = (EXACT && a.spread) ? (int)(threadIdx.x * gridDim.x + blockIdx.x) : (int)(blockIdx.x * a.lanes + threadIdx.x);
     bool live = (int)threadIdx.x < a.lanes && i0 < a.group;
     const int i1 = live ? i0 : a.group - 1;      // a lane without a trajectory shadows the last one and stores nothing
-    const int s = (EXACT && !DEFER && i1 >= a.n_back) ? a.defer[i1 - a.n_back] : a.s_first + a.s_step * i1;
+    const int s = (EXACT && i1 >= a.n_range) ? a.defer[i1 - a.n_range] : a.s_first + a.s_step * i1;
     const int S = a.N - 1;
     bool need_ls = false, cont = false;
     const SlotId sid = slot_id(a.idA[s]);

@@ -466,8 +466,10 @@ __device__ __forceinline__ double regu_coef(int r) { return ldexp(1.0, r) - 1.0;
 //   leaves Q(r) there.
 template <int n, int m>
 constexpr int scan_lds_doubles() { return REGU_GROUPS * QPack<n, m>::NL + REGU_GROUPS / 2; }
-template <int n, int m, int AUX>
-constexpr int stage_lds_doubles() { return scan_lds_doubles<n, m>() + 64 * (QPack<n, m>::NL + AUX); }
+template <int n, int m, int AUX, int PS = 64>
+constexpr int stage_lds_doubles() { return scan_lds_doubles<n, m>() + PS * (QPack<n, m>::NL + AUX); }
+constexpr int WIDE_TRAJ = 4;      // trajectories per wavefront, at most, in the launch for long regularisation loops
+constexpr int WIDE_PARK = 8;      // park places of that kernel
 
 // With ILQR_FLAG_LAPACK_EIGVALS every test is made the way NumPy makes it (eig_device.hpp) on the full matrix, both
 // triangles.  That needs, per wavefront, one matrix and its work space per lane, and the entries above the diagonal
@@ -518,7 +520,7 @@ struct PackedFull {
 // in which some lane took LAPACK's path; sites 0 round 0, 1 group scan, 2 stuck scan; [8] lanes in doubt, summed
 static __device__ unsigned long long g_dbg[16];
 // [0][b]: trajectory-passes of the second launch by 64-round trips of their own scans (bin b: 2^(b-1) < trips <= 2^b,
-// bin 0: none); [1][b]: the same per wavefront-pass (trips of all its trajectories)
+// bin 0: none); [1][b]: stages of those trajectories by the round their loop stopped at, same bins
 static __device__ unsigned long long g_hist[2][16];
 static __device__ int g_trips_lane;      // (unused placeholder so that the symbol list stays stable)
 __device__ __forceinline__ int dbg_bin(int t) { int b = 0; while ((1 << b) < t + 1 && b < 15) ++b; return b; }
@@ -548,6 +550,39 @@ __device__ __forceinline__ int exact_negative(const eig::Lane<n + m, 64>& E, con
         }
     }
 #endif
+    if (doubt) {
+        fill_full<n, m>(E, L, U);
+        v = E.has_negative();
+    }
+    return v;
+}
+// The same for candidates of one regularisation loop in round order, lane by lane, in the lanes `share` (this lane's
+// share of the wavefront: a mask of consecutive lanes; `have`: the share holds a loop): what is wanted is the first
+// lane whose matrix has no negative eigenvalue (or is not finite), so LAPACK's path is only taken by the lanes in
+// doubt BELOW the first lane of the share the screen is sure about.  Lanes above it return 1.
+template <int n, int m>
+__device__ __forceinline__ int exact_negative_ordered(const eig::Lane<n + m, 64>& E, const double* L, const double* U,
+                                                      bool have, unsigned long long share
+#ifdef ILQR_DEBUG_COUNTERS
+                                                      , int site
+#endif
+)
+{
+    int v = eig::screen<n + m>(PackedFull<n, m>{L, U});
+    const unsigned long long sure = __ballot(have && v == eig::SCREEN_NONE) & share;
+    const int first = sure ? __ffsll((long long)sure) - 1 : 64;
+    const bool doubt = have && (v == eig::SCREEN_DOUBT) && (int)(threadIdx.x & 63) < first;
+#ifdef ILQR_DEBUG_COUNTERS
+    {
+        const unsigned long long db = __ballot(doubt);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&g_dbg[2 * site], 1ull);
+            if (db) atomicAdd(&g_dbg[2 * site + 1], 1ull);
+            atomicAdd(&g_dbg[8 + site], (unsigned long long)__popcll(db));
+        }
+    }
+#endif
+    v = (!have || v == eig::SCREEN_DOUBT) ? 1 : v;
     if (doubt) {
         fill_full<n, m>(E, L, U);
         v = E.has_negative();
@@ -615,9 +650,13 @@ __device__ __forceinline__ double running_sum(double v, double p, int k0, int co
 // lane carries a trajectory); `lds` holds stage_lds_doubles() doubles.
 // Returns false on the LinAlgError cases.
 // ------------------------------------------------------------------
-// DEFER (with EXACT): a trajectory that is still failing after the group scan is not scanned further here: it is
+// EXACT with DEFER: a trajectory that is still failing after the group scan is not scanned further here: it is
 // reported in `deferred` and drops out of this pass (the caller runs its pass again in a launch whose wavefronts hold few
 // trajectories each, so that the long scans of different trajectories do not queue up in one wavefront).
+// EXACT without DEFER is the stage of that second kind of launch: no round 0 in the lane and no group scan; the
+// rounds 0, 1, 2, ... of every trajectory of the wavefront are tested 64 at a time, one trajectory after the other
+// (a trajectory that got here needs ~50 rounds at many stages: one LAPACK test of 64 lanes instead of three or four
+// one after the other).  Same matrices, same order, same counts as the other kernels.
 template <class M, bool EXACT = false, bool DEFER = false>
 __device__ __forceinline__ bool backward_stage(const double* par, double* xu, const double* next, double* Vx, double* V,
                                       double* dk, double* Kk, double& redu, int& regu_rounds, int& regu_stages,
@@ -638,9 +677,14 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
     const int lane = threadIdx.x & 63;
     double* const ldsP = lds;                                                   // P of the published trajectories
     int* const srcs = reinterpret_cast<int*>(lds + REGU_GROUPS * NL);           // their lanes
-    double* const park = lds + scan_lds_doubles<n, m>() + lane;                 // this lane's park, stride 64
+    // this lane's park, stride PS.  (WIDE: few lanes hold a trajectory; the others, which shadow one and store nothing
+    // that is read, share the last place.)
+    constexpr bool WIDE = EXACT && !DEFER;
+    constexpr int PS = WIDE ? WIDE_PARK : 64;
+    const int pslot = (lane < PS - 1) ? lane : PS - 1;
+    double* const park = lds + scan_lds_doubles<n, m>() + pslot;
     // EXACT: the lane's matrix and work space for the LAPACK path, and the published trajectories' upper entries
-    double* const exact0 = lds + stage_lds_doubles<n, m, TermsOf<M>::type::AUX>();
+    double* const exact0 = lds + stage_lds_doubles<n, m, TermsOf<M>::type::AUX, PS>();
     const eig::Lane<w, 64> E{exact0 + lane, exact0 + w * w * 64 + lane};
     double* const ldsQU = exact0 + (w * w + 2 * w) * 64;                                  // Q(0) above the diagonal
     double* const ldsPU = ldsQU + (REGU_GROUPS * (NUP > 0 ? NUP : 1) + 1) / 2 * 2;          // P above the diagonal
@@ -653,9 +697,9 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
         // (each is a long dependent chain of its own) and makes their register needs add up.
         ILQR_PHASE_BARRIER();
         ILQR_UNROLL
-        for (int e = 0; e < NL; ++e) park[e * 64] = QL[e];
+        for (int e = 0; e < NL; ++e) park[e * PS] = QL[e];
         ILQR_UNROLL
-        for (int e = 0; e < TR::AUX; ++e) park[(NL + e) * 64] = aux[e];
+        for (int e = 0; e < TR::AUX; ++e) park[(NL + e) * PS] = aux[e];
     }
     ILQR_PHASE_BARRIER();
     ILQR_MARK(load_next);
@@ -665,6 +709,11 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
 
     bool ok = true;
     int r = 0;
+    bool stuck_here = false;
+    if constexpr (WIDE) {
+        maxq = max_abs_packed<NL>(QL, maxq);      // round 0's matrix, by every lane as in the other kernels
+        stuck_here = alive;
+    } else {
     // ---- round 0 in every lane, in place (Q(0) itself is in the park), then the wavefront scans
     bool need;
     {
@@ -682,7 +731,6 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
     }
     ILQR_PHASE_BARRIER();
     if (need) regu_stages += 1;
-    bool stuck_here = false;
 
     // ---- group scan: rounds 1..REGU_BASE of up to REGU_GROUPS trajectories at once
     ILQR_MARK(group_scan);
@@ -792,14 +840,139 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
         }
         pend &= ~__ballot(src);
     }
+    }   // !WIDE
 
-    // ---- stuck scan: rounds REGU_BASE + 1, + 2, ... of one trajectory, 64 at a time
     ILQR_MARK(stuck_scan);
-    unsigned long long stuck = __ballot(stuck_here);
 #ifdef ILQR_DEBUG_COUNTERS
     const unsigned long long dbg_t0 = __builtin_readcyclecounter();
-    const bool dbg_any = stuck != 0;
+    const bool dbg_any = __ballot(stuck_here) != 0;
 #endif
+    if constexpr (WIDE) {
+        // ---- the loops of all trajectories of the wavefront (at most WIDE_TRAJ, in lanes 0..) side by side: the 64
+        // lanes are split evenly between the trajectories still looping, lane c of a trajectory's share tests round
+        // base + c of its running sum, whose state after `base` rounds (the checkpoint) waits in LDS; a trajectory
+        // whose share held no stop moves its checkpoint on by the share, one that stopped leaves, and the others get
+        // its lanes from the next trip on.
+        static_assert(WIDE_TRAJ * 2 <= REGU_GROUPS, "P and the checkpoints share the published slots");
+        double* const ckL = ldsP + WIDE_TRAJ * NL;                          // checkpoints, lower triangles
+        double* const ckU = ldsQU;                                          // ... entries above the diagonal
+        double* const outU = ldsQU + WIDE_TRAJ * (NUP > 0 ? NUP : 1);       // accepted matrix, entries above the diagonal
+        wave_sync();
+        if (stuck_here) {        // (lane < WIDE_TRAJ: the host launches this kernel with at most that many per wavefront)
+            double PL[NL], aux[TR::AUX];
+            ILQR_UNROLL
+            for (int e = 0; e < TR::AUX; ++e) aux[e] = park[(NL + e) * PS];
+            TR::regu_p_exact(aux, PL, PUown);
+            ILQR_UNROLL
+            for (int e = 0; e < NL; ++e) {
+                ldsP[lane * NL + e] = PL[e];
+                ckL[lane * NL + e] = park[e * PS];
+            }
+            ILQR_UNROLL
+            for (int e = 0; e < NUP; ++e) {
+                ldsPU[lane * NUP + e] = PUown[e];
+                ckU[lane * NUP + e] = QU[e];
+            }
+        }
+        int base = 0;
+        bool pending = stuck_here;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        for (;;) {
+            const unsigned long long pm = __ballot(pending);
+            if (!pm) break;
+            const int nu = __popcll(pm);
+            const int W = (nu == 1) ? 64 : (nu == 2) ? 32 : 16;      // lanes per trajectory in this trip
+            const int g = lane / W, c = lane - g * W;
+            int sg = 0;                                              // the lane that owns share g: the g-th pending one
+            {
+                int seen = 0;
+                ILQR_UNROLL
+                for (int b2 = 0; b2 < WIDE_TRAJ; ++b2) {
+                    const bool is = (pm >> b2) & 1ull;
+                    sg = (is && seen == g) ? b2 : sg;
+                    seen += is ? 1 : 0;
+                }
+            }
+            const bool have = g < nu;
+            const int bs = __shfl(base, sg);
+            const unsigned long long gm = ((W == 64) ? ~0ull : ((1ull << W) - 1ull)) << (g * W);
+            wave_sync();
+#ifdef ILQR_DEBUG_COUNTERS
+            if (pending) dbg_trips += 1;
+#endif
+            double mq = 0.0;
+            int t;
+            {
+                double L[NL], U[NUP > 0 ? NUP : 1];
+                ILQR_UNROLL
+                for (int e = 0; e < NL; ++e) L[e] = running_sum(ckL[sg * NL + e], ldsP[sg * NL + e], bs, c);
+                ILQR_UNROLL
+                for (int e = 0; e < NUP; ++e) U[e] = running_sum(ckU[sg * NUP + e], ldsPU[sg * NUP + e], bs, c);
+                mq = max_abs_packed<NL>(L, mq);
+                t = exact_negative_ordered<n, m>(E, L, U, have, gm ILQR_DBG_SITE(2));
+            }
+            const unsigned long long allstops = __ballot(have && t != 1);
+            const unsigned long long gstops = allstops & gm;
+            const int gwin = gstops ? __ffsll((long long)gstops) - 1 : -1;            // lane that stopped this share's loop
+            // largest |entry| as the other kernels take it: over rounds 1..REGU_BASE as far as the loop got, and the
+            // matrix it stopped at (round 0 was taken above)
+            {
+                const int rnd = bs + c;
+                const int rstar = gstops ? bs + (gwin - g * W) : 0x7fffffff;
+                double v = (have && rnd >= 1 && rnd <= rstar && (rnd <= REGU_BASE || rnd == rstar)) ? mq : 0.0;
+                ILQR_UNROLL
+                for (int dlt = 1; dlt < 64; dlt *= 2) {
+                    const double o = __shfl_xor(v, dlt);
+                    v = (dlt < W) ? fmax(v, o) : v;
+                }
+                mq = v;
+            }
+            wave_sync();
+            if (have && lane == gwin) {      // the accepted matrix, built again (the test destroyed it), to its owner
+                double* const dst = park - pslot + sg;
+                ILQR_UNROLL
+                for (int e = 0; e < NL; ++e) dst[e * PS] = running_sum(ckL[sg * NL + e], ldsP[sg * NL + e], bs, c);
+                ILQR_UNROLL
+                for (int e = 0; e < NUP; ++e) outU[sg * NUP + e] = running_sum(ckU[sg * NUP + e], ldsPU[sg * NUP + e], bs, c);
+            }
+            if (have && !gstops && c == W - 1) {      // no stop in this share: its checkpoint moves on by W rounds
+                ILQR_UNROLL
+                for (int e = 0; e < NL; ++e) ckL[sg * NL + e] = running_sum(ckL[sg * NL + e], ldsP[sg * NL + e], bs, W);
+                ILQR_UNROLL
+                for (int e = 0; e < NUP; ++e) ckU[sg * NUP + e] = running_sum(ckU[sg * NUP + e], ldsPU[sg * NUP + e], bs, W);
+            }
+            // the owners collect what their shares found
+            const int gi = __popcll(pm & below);                      // share of this lane's trajectory, if it has one
+            const int first = pending ? gi * W : 0;
+            const unsigned long long mine = pending ? (allstops & (((W == 64) ? ~0ull : ((1ull << W) - 1ull)) << first)) : 0ull;
+            const int swin = mine ? __ffsll((long long)mine) - 1 : first;
+            const int tw = __shfl(t, swin);
+            const double mqw = __shfl(mq, first);
+            wave_sync();
+            if (pending) {
+                maxq = fmax(maxq, mqw);
+                if (mine) {
+                    r = base + (swin - first);
+#ifdef ILQR_DEBUG_COUNTERS
+                    atomicAdd(&g_hist[1][dbg_bin(r)], 1ull);
+#endif
+                    if (r >= 1) regu_stages += 1;
+                    ILQR_UNROLL
+                    for (int e = 0; e < NUP; ++e) QU[e] = outU[lane * NUP + e];
+                    ok = ok && (tw >= 0);
+                    pending = false;
+                } else {
+                    base += W;
+                    if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
+                        ok = false;
+                        pending = false;
+                    }
+                }
+            }
+        }
+    } else if constexpr (!EXACT) {
+    // ---- stuck scan: rounds REGU_BASE + 1, + 2, ... of one trajectory, 64 at a time
+    unsigned long long stuck = __ballot(stuck_here);
     while (stuck) {
         const int src = __ffsll((long long)stuck) - 1;
         stuck &= stuck - 1;
@@ -808,127 +981,56 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
             double PL[NL], aux[TR::AUX];
             ILQR_UNROLL
             for (int e = 0; e < TR::AUX; ++e) aux[e] = park[(NL + e) * 64];
-            if constexpr (EXACT) TR::regu_p_exact(aux, PL, PUown);
-            else TR::regu_p(aux, PL);
+            TR::regu_p(aux, PL);
             ILQR_UNROLL
             for (int e = 0; e < NL; ++e) ldsP[e] = PL[e];
-            if constexpr (EXACT) {
-                ILQR_UNROLL
-                for (int e = 0; e < NUP; ++e) ldsPU[e] = PUown[e];
-            }
         }
-        if constexpr (EXACT) {
-            // The running sum after `base` rounds waits in LDS (lower triangle behind P, upper entries where Q(0)'s
-            // were published); lane l adds l further rounds to it, and when none of the 64 stops the test the
-            // checkpoint moves on by 64 rounds.
-            double* const ckL = ldsP + NL;
-            double* const ckU = ldsQU;
-            double* const outU = ldsQU + (NUP > 0 ? NUP : 1);
-            if (lane == src) {
-                ILQR_UNROLL
-                for (int e = 0; e < NL; ++e) ckL[e] = running_sum(park[e * 64], ldsP[e], 0, REGU_BASE + 1);
-                ILQR_UNROLL
-                for (int e = 0; e < NUP; ++e) ckU[e] = running_sum(QU[e], PUown[e], 0, REGU_BASE + 1);
-            }
-            for (int base = REGU_BASE + 1;; base += 64) {
+        for (int base = REGU_BASE + 1;; base += 64) {
+            wave_sync();     // P and Q(0) are read from LDS again on every trip, not held in registers across the loop
+            double L[NL];
+            build_regularised<NL>(L, regu_coef(base + lane), ldsP, park - lane + src);
+            double mq = 0.0;
+            int t;
+            t = has_negative_eig_packed<w, UF>(L, mq);
+            const unsigned long long stops = __ballot(t != 1);
+            if (stops) {
+                const int win = __ffsll((long long)stops) - 1;
+                const int tw = __shfl(t, win);
+                const double mqw = __shfl(mq, win);
                 wave_sync();
-#ifdef ILQR_DEBUG_COUNTERS
-                if (lane == src) dbg_trips += 1;
-#endif
-                double mq = 0.0;
-                int t;
-                {
-                    double L[NL], U[NUP > 0 ? NUP : 1];
+                if (lane == src) {
+                    r = base + win;
+                    const double cw = regu_coef(r);
+                    double pe[NL], q0[NL];
                     ILQR_UNROLL
-                    for (int e = 0; e < NL; ++e) L[e] = running_sum(ckL[e], ldsP[e], base, lane);
+                    for (int e = 0; e < NL; ++e) pe[e] = ldsP[e];
                     ILQR_UNROLL
-                    for (int e = 0; e < NUP; ++e) U[e] = running_sum(ckU[e], ldsPU[e], base, lane);
-                    mq = max_abs_packed<NL>(L, mq);
-                    bool sdoubt;
-                    t = exact_negative<n, m>(E, L, U, true, sdoubt ILQR_DBG_SITE(2));
-                }
-                const unsigned long long stops = __ballot(t != 1);
-                if (stops) {
-                    const int win = __ffsll((long long)stops) - 1;
-                    const int tw = __shfl(t, win);
-                    const double mqw = __shfl(mq, win);
-                    wave_sync();
-                    if (lane == win) {      // the accepted matrix, built again (the test destroyed it), to its owner
-                        double* const dst = park - lane + src;
+                    for (int e = 0; e < NL; ++e) q0[e] = park[e * 64];
+                    ILQR_PHASE_BARRIER();
+                    ILQR_UNROLL
+                    for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(cw, pe[e], q0[e]);
+                    ILQR_UNROLL
+                    for (int i = 0; i < n; ++i)
                         ILQR_UNROLL
-                        for (int e = 0; e < NL; ++e) dst[e * 64] = running_sum(ckL[e], ldsP[e], base, win);
-                        ILQR_UNROLL
-                        for (int e = 0; e < NUP; ++e) outU[e] = running_sum(ckU[e], ldsPU[e], base, win);
-                    }
-                    wave_sync();
-                    if (lane == src) {
-                        r = base + win;
-                        ILQR_UNROLL
-                        for (int e = 0; e < NUP; ++e) QU[e] = outU[e];
-                        ok = ok && (tw >= 0);
-                        maxq = fmax(maxq, mqw);
-                    }
-                    break;
-                }
-                if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
-                    if (lane == src) ok = false;
-                    break;
-                }
-                wave_sync();
-                if (lane == 63) {
+                        for (int j = i + 1; j < n; ++j)
+                            QU[upp(n, i, j)] = __builtin_fma(cw, ldsP[tri(j, i)], QU[upp(n, i, j)]);
                     ILQR_UNROLL
-                    for (int e = 0; e < NL; ++e) ckL[e] = running_sum(ckL[e], ldsP[e], base, 64);
-                    ILQR_UNROLL
-                    for (int e = 0; e < NUP; ++e) ckU[e] = running_sum(ckU[e], ldsPU[e], base, 64);
+                    for (int i = 0; i < m; ++i)
+                        ILQR_UNROLL
+                        for (int j = i + 1; j < m; ++j)
+                            QU[upp(m, i, j, QP::UUB)] = __builtin_fma(cw, ldsP[tri(n + j, n + i)], QU[upp(m, i, j, QP::UUB)]);
+                    ok = ok && (tw >= 0);
+                    maxq = fmax(maxq, mqw);
                 }
+                break;
             }
-        } else {
-            for (int base = REGU_BASE + 1;; base += 64) {
-                wave_sync();     // P and Q(0) are read from LDS again on every trip, not held in registers across the loop
-                double L[NL];
-                build_regularised<NL>(L, regu_coef(base + lane), ldsP, park - lane + src);
-                double mq = 0.0;
-                int t;
-                t = has_negative_eig_packed<w, UF>(L, mq);
-                const unsigned long long stops = __ballot(t != 1);
-                if (stops) {
-                    const int win = __ffsll((long long)stops) - 1;
-                    const int tw = __shfl(t, win);
-                    const double mqw = __shfl(mq, win);
-                    wave_sync();
-                    if (lane == src) {
-                        r = base + win;
-                        const double cw = regu_coef(r);
-                        double pe[NL], q0[NL];
-                        ILQR_UNROLL
-                        for (int e = 0; e < NL; ++e) pe[e] = ldsP[e];
-                        ILQR_UNROLL
-                        for (int e = 0; e < NL; ++e) q0[e] = park[e * 64];
-                        ILQR_PHASE_BARRIER();
-                        ILQR_UNROLL
-                        for (int e = 0; e < NL; ++e) park[e * 64] = __builtin_fma(cw, pe[e], q0[e]);
-                        ILQR_UNROLL
-                        for (int i = 0; i < n; ++i)
-                            ILQR_UNROLL
-                            for (int j = i + 1; j < n; ++j)
-                                QU[upp(n, i, j)] = __builtin_fma(cw, ldsP[tri(j, i)], QU[upp(n, i, j)]);
-                        ILQR_UNROLL
-                        for (int i = 0; i < m; ++i)
-                            ILQR_UNROLL
-                            for (int j = i + 1; j < m; ++j)
-                                QU[upp(m, i, j, QP::UUB)] = __builtin_fma(cw, ldsP[tri(n + j, n + i)], QU[upp(m, i, j, QP::UUB)]);
-                        ok = ok && (tw >= 0);
-                        maxq = fmax(maxq, mqw);
-                    }
-                    break;
-                }
-                if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
-                    if (lane == src) ok = false;
-                    break;
-                }
+            if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
+                if (lane == src) ok = false;
+                break;
             }
         }
     }
+    }   // (EXACT with DEFER: a trajectory that would get here has been dropped from the pass)
 #ifdef ILQR_DEBUG_COUNTERS
     if (dbg_any && (threadIdx.x & 63) == 0) atomicAdd(&g_dbg[12], __builtin_readcyclecounter() - dbg_t0);     // cycles in stuck scans
 #endif
@@ -939,7 +1041,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
     ILQR_PHASE_BARRIER();
     ILQR_MARK(gains_v);
     ILQR_UNROLL
-    for (int e = 0; e < NL; ++e) QL[e] = park[e * 64];      // Q(r)
+    for (int e = 0; e < NL; ++e) QL[e] = park[e * PS];      // Q(r)
 
     // ---- gains (iLQRController.py:125-129): d = -Quu^-1 Qu, K = -Quu^-1 Qux
     double Quu[m * m], Qinv[m * m];
@@ -1166,9 +1268,6 @@ __device__ __forceinline__ bool backward_pass(const double* par, const RecIn& T,
 #ifdef ILQR_DEBUG_COUNTERS
     if (EXACT && !DEFER) {
         if (active) atomicAdd(&g_hist[0][dbg_bin(dbg_trips)], 1ull);
-        int tot = dbg_trips;
-        for (int d = 32; d >= 1; d /= 2) tot += __shfl_xor(tot, d);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&g_hist[1][dbg_bin(tot)], 1ull);
     }
 #endif
     return ok;

@@ -35,7 +35,7 @@ for k, name in enumerate(("round 0", "group scan", "stuck scan")):
 L.ilqr_debug_histograms(hist, 1)
 h = list(hist)
 print("second launches, 64-round trips per trajectory-pass, bins 0, 1, 2, <=4, <=8, ...:", h[:14])
-print("second launches, trips per wavefront-pass,           bins 0, 1, 2, <=4, <=8, ...:", h[16:30])
+print("second launches, stages by the round the loop stopped at,   bins 0, 1, 2, <=4, <=8, ...:", h[16:30])
 trips = max(v[4], 1)
 print(f"stuck scans: {v[12] / 1e6:.1f} Mcycles in total, {v[12] / trips:.0f} cycles per 64-round trip")
 print(f"passes of wavefronts: first launches {v[6]} passes, {v[13] / max(v[6], 1):.0f} cycles each; second launches {v[7]} passes, "
