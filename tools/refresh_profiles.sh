@@ -21,6 +21,12 @@ python tools/trace_summary.py $out/kt 3 > $out/kernel_trace_summary.txt
 python tools/trace_summary.py $out/kt1 3 > $out/kernel_trace_summary_single_stream.txt
 timeout -k 10 600 python bench.py --steps 5 > $out/bench_line.json 2> $out/bench.err
 tail -c 1500 $out/bench_line.json
+# the same batch under ILQR_FLAG_LAPACK_EIGVALS (three backward launches per iteration and part)
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktf -- python3 $R/tools/faithful_probe.py 1048576 0 1 > $out/ktf.log 2>&1
+cd $R
+cp $(ls $out/ktf/*/*kernel_stats.csv | head -1) $out/kernel_stats_lapack_eigvals.csv
+python tools/trace_summary.py $out/ktf 3 > $out/kernel_trace_summary_lapack_eigvals.txt || true
 # where the wavefronts' cycles go (single stream; last, so that trouble with a counter name costs nothing else)
 cd /tmp
 ILQR_HIP_PARTS=1 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d $out/sq -- $B > $out/sq.log 2>&1

@@ -10,10 +10,13 @@ it = 0
 lines = []
 for r in pipe:
     name = re.search(r"pipe_(\w+?)_kernel", r["Kernel_Name"]).group(1)
+    # ILQR_FLAG_LAPACK_EIGVALS: the launches that drop long regularisation loops and the launch that runs them
+    if name == "backward" and re.search(r"true, true>", r["Kernel_Name"]): name = "backward_lapack"
+    elif name == "backward" and re.search(r"true, false>", r["Kernel_Name"]): name = "backward_lapack_long"
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     tot[name] += dur; calls[name] += 1
     if name == "init": it = 0
-    if name == "backward": it += 1
+    if name in ("backward", "backward_lapack"): it += 1
     lines.append((it, name, int(r["Grid_Size_X"]) // 64, dur, r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("Scratch_Size"), r.get("LDS_Block_Size")))
 span = (int(pipe[-1]["End_Timestamp"]) - int(pipe[0]["Start_Timestamp"])) / 1e6
 print(f"pipeline span {span:.2f} ms over {len(pipe)} launches; sum of kernel time {sum(tot.values()):.2f} ms")
