@@ -321,18 +321,27 @@ struct TeamOps<UserModel> {
 // test made the way NumPy makes it (eig_device.hpp: DGEEV restated) on the full 16 x 16 matrix, one matrix per lane.
 // A team's lanes hold the rows of Q and of P = (0.1 F)'F; they are published in LDS, the upper right block as the
 // mirror image of the lower left one (the reference assembles Q from Q_xx, Q_ux, Q_uu, :139-147), and then
-//   trip 0: lane 8 t + c tests round c of team t (c = 0..7),
-//   a team still failing is scanned 32 rounds per trip, lane l testing round base + l,
+//   trip 0: lane R0 t + c tests round c of team t (c = 0..R0-1, R0 = TXL / 4),
+//   a team still failing is scanned TXL rounds per trip, lane l testing round base + l,
 // round r being the reference's running sum Q(r) = Q(r - 1) + 2^(r-1) P (r rounded additions, not one product).
-// LDS: 32 matrices with their work space, the four teams' Q(0) and P, two checkpoints of the running sum.
+// LDS: TXL matrices with their work space, the four teams' Q(0) and P, two checkpoints of the running sum.  One test
+// takes as long for 1 matrix as for 64 (per-lane loops, one wavefront per CU), so TXL is as many matrices as the
+// 160 KB of a CU hold next to the rest of the kernel (team_exact_lanes below).
 // ------------------------------------------------------------------
-constexpr int TX_LANES = 32;
-constexpr int TX_EIG = (16 * 16 + 2 * 16) * TX_LANES;
 constexpr int TX_PUB = (PIPE_WG / TEAM_LANES) * 2 * 256;
-constexpr int TEAM_EXACT_LDS = TX_EIG + TX_PUB + 2 * 256;
+constexpr int TX_PER_LANE = 16 * 16 + 2 * 16;
+constexpr int team_exact_lds(int txl) { return TX_PER_LANE * txl + TX_PUB + 2 * 256; }
+// matrices per test for a kernel whose other LDS arrays hold `other` doubles: a multiple of 4, at most 64
+constexpr int team_exact_lanes(int other)
+{
+    int t = ((160 * 1024 - 256) / 8 - other - TX_PUB - 2 * 256) / TX_PER_LANE;
+    t = t / 4 * 4;
+    return t > 64 ? 64 : t;
+}
 
 // the lane's matrix: q + (2^k0 + ... + 2^(k0 + nr - 1)) p, added one term after the other; q, p row-major 16 x 16
-__device__ __forceinline__ void team_exact_build(const eig::Lane<16, TX_LANES>& E, const double* q, const double* p,
+template <int TXL>
+__device__ __forceinline__ void team_exact_build(const eig::Lane<16, TXL>& E, const double* q, const double* p,
                                                  int k0, int nr, double& mq)
 {
 #pragma clang fp contract(off)
@@ -343,18 +352,23 @@ __device__ __forceinline__ void team_exact_build(const eig::Lane<16, TX_LANES>& 
         for (int i = 0; i < nr; ++i) s += ldexp(pe, k0 + i);
         const double as = __builtin_fabs(s);
         mq = (as > mq) ? as : mq;
-        E.a[((e >> 4) + (e & 15) * 16) * TX_LANES] = s;
+        E.a[((e >> 4) + (e & 15) * 16) * TXL] = s;
     }
 }
 
 // Qrow, Prow: row j of the team's Q(0) and P (in: as computed; out: Q(r), and P with the mirrored block).
 // r: rounds taken; verdict: the last test's (0 = accepted, -1 = NumPy raises LinAlgError).  All 64 lanes call together.
+template <int TXL>
 __device__ __forceinline__ void team_regularise_exact(double* Qrow, double* Prow, int lane, int team, int j, bool alive,
                                                       double* X, int& r, int& verdict, double& maxq)
 {
 #pragma clang fp contract(off)
     constexpr int n = 12, m = 4, w = 16;
-    const eig::Lane<16, TX_LANES> E{X + (lane & (TX_LANES - 1)), X + 256 * TX_LANES + (lane & (TX_LANES - 1))};
+    static_assert(TXL % 4 == 0 && TXL >= 8 && TXL <= 64, "matrices per test");
+    constexpr int R0 = TXL / 4;                  // rounds per team in trip 0
+    constexpr int TX_EIG = TX_PER_LANE * TXL;
+    const int el = lane < TXL ? lane : TXL - 1;  // (lanes beyond TXL test nothing)
+    const eig::Lane<16, TXL> E{X + el, X + 256 * TXL + el};
     double* const pubQ = X + TX_EIG;
     double* const pubP = pubQ + (PIPE_WG / TEAM_LANES) * 256;
     double* ck = X + TX_EIG + TX_PUB;
@@ -382,30 +396,30 @@ __device__ __forceinline__ void team_regularise_exact(double* Qrow, double* Prow
     }
     wave_sync();
 
-    // ---- trip 0: rounds 0..7 of the four teams
+    // ---- trip 0: rounds 0..R0-1 of the four teams
     bool stuck = false;
     {
         int t = 1;
         double mq = 0.0;
-        const int tt = (lane >> 3) & 3, c = lane & 7;
-        if (lane < TX_LANES) {
-            team_exact_build(E, pubQ + tt * 256, pubP + tt * 256, 0, c, mq);
+        const int tt = (lane < TXL) ? lane / R0 : 0, c = lane - tt * R0;
+        if (lane < TXL) {
+            team_exact_build<TXL>(E, pubQ + tt * 256, pubP + tt * 256, 0, c, mq);
             t = E.has_negative();
         }
-        const unsigned long long passed = __ballot(lane < TX_LANES && t != 1);
-        const int byte = (int)((passed >> (8 * team)) & 0xFFull);
-        const int cstar = byte ? __ffs(byte) - 1 : -1;
-        const int lim = (cstar >= 0) ? cstar : 7;
-        const int tv = __shfl(t, 8 * team + lim);
+        const unsigned long long passed = __ballot(lane < TXL && t != 1);
+        const int bits = (int)((passed >> (R0 * team)) & ((1ull << R0) - 1ull));
+        const int cstar = bits ? __ffs(bits) - 1 : -1;
+        const int lim = (cstar >= 0) ? cstar : R0 - 1;
+        const int tv = __shfl(t, R0 * team + lim);
         double mqt = 0.0;
 #pragma unroll
-        for (int c2 = 0; c2 < 8; ++c2) {
-            const double v = __shfl(mq, 8 * team + c2);
+        for (int c2 = 0; c2 < R0; ++c2) {
+            const double v = __shfl(mq, R0 * team + c2);
             mqt = (c2 <= lim && v > mqt) ? v : mqt;
         }
         if (alive) {
             maxq = (mqt > maxq) ? mqt : maxq;
-            r = (cstar >= 0) ? cstar : 8;
+            r = (cstar >= 0) ? cstar : R0;
             verdict = tv;
             stuck = cstar < 0;
         } else {
@@ -422,7 +436,7 @@ __device__ __forceinline__ void team_regularise_exact(double* Qrow, double* Prow
         }
     }
 
-    // ---- teams still failing after round 7, one after the other, 32 rounds per trip
+    // ---- teams still failing after round R0 - 1, one after the other, TXL rounds per trip
     unsigned long long todo = __ballot(stuck);
 #pragma unroll 1
     while (todo) {
@@ -431,23 +445,23 @@ __device__ __forceinline__ void team_regularise_exact(double* Qrow, double* Prow
         const double* const q0 = pubQ + tq * 256;
         const double* const pp = pubP + tq * 256;
         wave_sync();
-        for (int e = lane; e < 256; e += 64) {       // checkpoint: the sum after 8 rounds
+        for (int e = lane; e < 256; e += 64) {       // checkpoint: the sum after R0 rounds
             double s = q0[e];
-            for (int k = 0; k < 8; ++k) s += ldexp(pp[e], k);
+            for (int k = 0; k < R0; ++k) s += ldexp(pp[e], k);
             ck[e] = s;
         }
         double mqs = 0.0;
 #pragma unroll 1
-        for (int base = 8;; base += TX_LANES) {
+        for (int base = R0;; base += TXL) {
             wave_sync();
             int t = 1;
             double mq = 0.0;
-            if (lane < TX_LANES) {
-                team_exact_build(E, ck, pp, base, lane, mq);
+            if (lane < TXL) {
+                team_exact_build<TXL>(E, ck, pp, base, lane, mq);
                 t = E.has_negative();
             }
-            const unsigned long long stops = __ballot(lane < TX_LANES && t != 1);
-            const int win = stops ? __ffsll((long long)stops) - 1 : TX_LANES - 1;
+            const unsigned long long stops = __ballot(lane < TXL && t != 1);
+            const int win = stops ? __ffsll((long long)stops) - 1 : TXL - 1;
             double v = (lane <= win) ? mq : 0.0;
 #pragma unroll
             for (int dlt = 1; dlt < 64; dlt *= 2) {
@@ -475,16 +489,16 @@ __device__ __forceinline__ void team_regularise_exact(double* Qrow, double* Prow
                 }
                 break;
             }
-            if (base + TX_LANES > TEAM_REGU_MAX) {      // 0.1 * 2^r overflowed long before: cannot happen, but never spin
+            if (base + TXL > TEAM_REGU_MAX) {      // 0.1 * 2^r overflowed long before: cannot happen, but never spin
                 if (team == tq) {
-                    r = base + TX_LANES;
+                    r = base + TXL;
                     verdict = -1;
                 }
                 break;
             }
-            for (int e = lane; e < 256; e += 64) {       // next checkpoint: 32 rounds further
+            for (int e = lane; e < 256; e += 64) {       // next checkpoint: TXL rounds further
                 double s = ck[e];
-                for (int i = 0; i < TX_LANES; ++i) s += ldexp(pp[e], base + i);
+                for (int i = 0; i < TXL; ++i) s += ldexp(pp[e], base + i);
                 ckn[e] = s;
             }
             double* const sw = ck;
@@ -515,7 +529,9 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
     constexpr int TEAM_ALL = TEAM_LDS + OPS::EXTRA;
     __shared__ double lds_all[(PIPE_WG / TEAM_LANES) * TEAM_ALL];
     __shared__ double shared_all[OPS::SHARED > 0 ? (PT ? PIPE_WG / TEAM_LANES : 1) * OPS::SHARED : 1];
-    __shared__ double exact_all[EXACT ? TEAM_EXACT_LDS : 1];
+    constexpr int OTHER_LDS = (PIPE_WG / TEAM_LANES) * TEAM_ALL + (OPS::SHARED > 0 ? (PT ? PIPE_WG / TEAM_LANES : 1) * OPS::SHARED : 1);
+    constexpr int TXL = team_exact_lanes(OTHER_LDS);
+    __shared__ double exact_all[EXACT ? team_exact_lds(TXL) : 1];
     const int lane = threadIdx.x & 63, team = lane / TEAM_LANES, j = lane % TEAM_LANES;
     const unsigned long long tmask = 0xFFFFull << (team * TEAM_LANES);
     double* const L = lds_all + team * TEAM_ALL;
@@ -617,7 +633,7 @@ __global__ __launch_bounds__(PIPE_WG) void pipe_backward_team_kernel(Pipe a)
         // scan whenever "has a negative eigenvalue" does not switch back on as r grows, in ~20 tests.
         if constexpr (EXACT) {
             int r = 0, verdict = 0;
-            team_regularise_exact(Qrow, Prow, lane, team, j, alive, exact_all, r, verdict, maxq);
+            team_regularise_exact<TXL>(Qrow, Prow, lane, team, j, alive, exact_all, r, verdict, maxq);
             ok = ok && (verdict >= 0);
             if (alive && r > 0) rs += 1;
             rr += r;
