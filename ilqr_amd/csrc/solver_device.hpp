@@ -452,6 +452,9 @@ __device__ inline int has_negative_eig_packed(double* L, double& maxq)
 //   stuck scan: a trajectory still failing after REGU_BASE rounds publishes
 //     Q(REGU_BASE) and P; lane l tests Q(REGU_BASE + 1 + l), then +64, ...
 // ------------------------------------------------------------------
+#ifndef ILQR_SCAN_LIMIT
+#define ILQR_SCAN_LIMIT 1200     // (a smaller value cuts long scans short: timing experiments only)
+#endif
 constexpr int REGU_BASE = 8;      // rounds covered by the group scan (or lane by lane for the big plants)
 constexpr int REGU_GROUPS = 8;    // trajectories per group scan; REGU_GROUPS * REGU_BASE == 64
 
@@ -1024,7 +1027,7 @@ __device__ __forceinline__ bool backward_stage(const double* par, double* xu, co
                 }
                 break;
             }
-            if (base > 1200) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
+            if (base > ILQR_SCAN_LIMIT) {   // 0.1 * 2^r overflowed long before: cannot happen, but never spin
                 if (lane == src) ok = false;
                 break;
             }
