@@ -522,10 +522,10 @@ struct PackedFull {
 // build-time diagnostics (tools/debug_counters.py): [2 site] calls of exact_negative by a wavefront, [2 site + 1] those
 // in which some lane took LAPACK's path; sites 0 round 0, 1 group scan, 2 stuck scan; [8] lanes in doubt, summed
 static __device__ unsigned long long g_dbg[16];
-// [0][b]: trajectory-passes of the second launch by 64-round trips of their own scans (bin b: 2^(b-1) < trips <= 2^b,
-// bin 0: none); [1][b]: stages of those trajectories by the round their loop stopped at, same bins
+// [0][b]: trajectory-passes of the launch for long regularisation loops by the trips (LAPACK tests of the wavefront) their
+// loops took part in (bin b: 2^(b-1) < trips <= 2^b, bin 0: none); [1][b]: stages of those trajectories by the round their
+// loop stopped at, same bins
 static __device__ unsigned long long g_hist[2][16];
-static __device__ int g_trips_lane;      // (unused placeholder so that the symbol list stays stable)
 __device__ __forceinline__ int dbg_bin(int t) { int b = 0; while ((1 << b) < t + 1 && b < 15) ++b; return b; }
 #define ILQR_DBG_SITE(k) , (k)
 #else

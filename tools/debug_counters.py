@@ -29,14 +29,14 @@ r = s.solve(x0, u0)
 torch.cuda.synchronize()
 L.ilqr_debug_counters(out, 1)
 v = list(out)
-for k, name in enumerate(("round 0", "group scan", "stuck scan")):
+for k, name in enumerate(("round 0", "group scan", "long loops")):
     print(f"{name:11s}: wavefront calls {v[2 * k]:10d}, with LAPACK {v[2 * k + 1]:10d} ({v[2 * k + 1] / max(v[2 * k], 1):.3f}), "
           f"lanes in doubt per call {v[8 + k] / max(v[2 * k], 1):.2f}")
 L.ilqr_debug_histograms(hist, 1)
 h = list(hist)
-print("second launches, 64-round trips per trajectory-pass, bins 0, 1, 2, <=4, <=8, ...:", h[:14])
-print("second launches, stages by the round the loop stopped at,   bins 0, 1, 2, <=4, <=8, ...:", h[16:30])
+print("launch for long loops, tests per trajectory-pass,        bins 0, 1, 2, <=4, <=8, ...:", h[:14])
+print("launch for long loops, stages by the round the loop stopped at, bins 0, 1, 2, <=4, <=8, ...:", h[16:30])
 trips = max(v[4], 1)
-print(f"stuck scans: {v[12] / 1e6:.1f} Mcycles in total, {v[12] / trips:.0f} cycles per 64-round trip")
-print(f"passes of wavefronts: first launches {v[6]} passes, {v[13] / max(v[6], 1):.0f} cycles each; second launches {v[7]} passes, "
+print(f"long loops: {v[12] / 1e6:.1f} Mcycles in total, {v[12] / trips:.0f} cycles per test of 64 matrices")
+print(f"passes of wavefronts: the two launches that drop long loops {v[6]} passes, {v[13] / max(v[6], 1):.0f} cycles each; the launch for long loops {v[7]} passes, "
       f"{v[14] / max(v[7], 1):.0f} cycles each; longest pass {v[15]} cycles")
