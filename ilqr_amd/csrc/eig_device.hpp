@@ -243,6 +243,38 @@ struct Lane {
         return true;
     }
 
+    // True when DGEBAL('B') provably leaves the matrix as it is (ilo = 1, ihi = W, no scaling), decided without its
+    // extended-precision norms.  The permutation phase moves nothing unless a row or a column is zero off the diagonal.
+    // The scaling phase leaves row/column i alone when c >= r / 2 and c / 2 < r (c, r the 2-norms of column and row i:
+    // neither of its loops runs, f stays 1 and c + r >= 0.95 (c + r)); here that is asked of plainly summed squares
+    // with room for their rounding, 0.26 r^2 <= c^2 <= 3.9 r^2, both non-zero.  Entries are finite and, after DGEEV's
+    // own scaling, far from the overflow of a square.  Anything else takes gebal() itself.
+    __device__ bool gebal_is_identity() const
+    {
+        double r2[W], c2[W];
+        bool rz[W], cz[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) { r2[i] = 0.0; c2[i] = 0.0; rz[i] = true; cz[i] = true; }
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const double v = a[(i + j * W) * ES];
+                const double q = v * v;
+                r2[i] += q;
+                c2[j] += q;
+                if (i != j) {
+                    rz[i] = rz[i] && (v == 0.0);
+                    cz[j] = cz[j] && (v == 0.0);
+                }
+            }
+        bool same = true;
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            same = same && !rz[i] && !cz[i] && (c2[i] > 0.0) && (r2[i] > 0.0) && (c2[i] >= 0.26 * r2[i]) && (c2[i] <= 3.9 * r2[i]);
+        return same;
+    }
+
     // ---- DGEMV / DGER as OpenBLAS' AVX2 / AVX-512 kernels evaluate them (c = first entry, stride ES per row,
     //      W * ES per column) ----
     // work[j] = sum_i C(i, j) v(i), j < n: rows in blocks of four -- columns four at a time with one fused 4-lane
@@ -691,8 +723,10 @@ struct Lane {
         // (the eigenvalues are only compared with zero: scaling them back by a positive factor changes nothing)
         if (anrm > 0.0 && anrm < smlnum) lascl(anrm, smlnum);
         else if (anrm > bignum) lascl(anrm, bignum);
-        int ilo, ihi;
-        if (!gebal(ilo, ihi)) return -1;
+        int ilo = 1, ihi = W;
+        if (!gebal_is_identity()) {
+            if (!gebal(ilo, ihi)) return -1;
+        }
         gehd2(ilo, ihi);
         bool neg = false;
         for (int i = 1; i <= ilo - 1; ++i) neg = neg || (A(i, i) < 0.0);
