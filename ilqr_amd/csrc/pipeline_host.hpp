@@ -114,6 +114,7 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
         a.count = (int)count;
         a.iter = iter;
         a.s_first = 0; a.s_step = 1; a.group = (int)(count - back); a.lanes = PIPE_WG; a.n_range = a.group; a.spread = 0;
+        a.back_blocks = 0; a.back_group = 0; a.back_lanes = 1;
         // Latency-bound regime (about one wavefront per SIMD or less): fewer, wider launches per iteration.
         // The schedule does not change any result, so neither does the threshold.
         const bool tail = count <= TAIL_COUNT && a.max_ls >= 2 &&
@@ -134,25 +135,25 @@ int run_part(Pipe a, hipStream_t st, ilqr_timing* tout)
                                    dim3(PIPE_WG), 0, st, a);
             }
         } else if (a.flags & ILQR_FLAG_LAPACK_EIGVALS) {
-            // Three launches (Pipe::s_first).  The first two drop and list a trajectory at the stage where it turns out
-            // to need a long scan; the third runs the listed ones again from their last stage, few per wavefront.
-            // The back and the list are spread thinly: as few per wavefront as still gives every SIMD its wavefronts
-            // (three workgroups of this kernel fit a CU).  Results do not depend on any of it.
+            // Two launches (Pipe::s_first).  The first covers the back and the front of the slot buffer, in that order of
+            // workgroups, and drops and lists a trajectory at the stage where it turns out to need a long scan; the second
+            // runs the listed ones again from their last stage, few per wavefront.  The back and the list are spread
+            // thinly: as few per wavefront as still gives every SIMD its wavefronts (three workgroups of the first
+            // kernel fit a CU, four of the second).  Results do not depend on any of it.
             long resident = 768 / (a.parts > 0 ? a.parts : 1);
             if (const char* e = getenv("ILQR_HIP_DIRTY_WAVES")) resident = atol(e);     // for tuning
-            if (a.group > 0)
-                hipLaunchKernelGGL((pipe_backward_kernel<M, PT, true, true>), dim3(blocks_for(a.group, PIPE_WG)), dim3(PIPE_WG), 0,
-                                   st, a);
-            if (back > 0) {
+            {
                 Pipe b = a;
-                b.s_first = (int)a.B - 1; b.s_step = -1; b.group = (int)back; b.n_range = (int)back; b.spread = 1;
-                long most = 16;
-                if (const char* e = getenv("ILQR_HIP_DIRTY_LANES")) most = atol(e);        // for tuning
-                int lanes = 1;
-                while (lanes < most && (long)blocks_for(b.group, 2 * lanes) >= resident) lanes *= 2;
-                b.lanes = lanes;
-                hipLaunchKernelGGL((pipe_backward_kernel<M, PT, true, true>), dim3(blocks_for(b.group, lanes)), dim3(PIPE_WG), 0,
-                                   st, b);
+                if (back > 0) {
+                    long most = 16;
+                    if (const char* e = getenv("ILQR_HIP_DIRTY_LANES")) most = atol(e);        // for tuning
+                    int lanes = 1;
+                    while (lanes < most && (long)blocks_for(back, 2 * lanes) >= resident) lanes *= 2;
+                    b.back_lanes = lanes; b.back_group = (int)back; b.back_blocks = (int)blocks_for(back, lanes);
+                }
+                const unsigned blocks = (unsigned)b.back_blocks + (b.group > 0 ? blocks_for(b.group, PIPE_WG) : 0u);
+                if (blocks > 0)
+                    hipLaunchKernelGGL((pipe_backward_kernel<M, PT, true, true>), dim3(blocks), dim3(PIPE_WG), 0, st, b);
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h, a.cnt + CNT_DEFER, sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -95,11 +95,15 @@ struct Pipe {
     // s_first + i * s_step, the entries after those are the slots listed in `defer`.
     // With ILQR_FLAG_LAPACK_EIGVALS slots are handed out from both ends of the buffer: trajectories whose tests the
     // certified screen has settled so far from the front, the others ("dirty": they run LAPACK's path at most
-    // stages) from the back, so that a wavefront holds one kind, and an iteration's backward pass is three launches:
-    // the front, 64 per wavefront; the back, fewer per wavefront; and, one or two per wavefront, the trajectories
+    // stages) from the back, so that a wavefront holds one kind, and an iteration's backward pass covers three ranges:
+    // the front, 64 per wavefront; the back, fewer per wavefront; and, at most four per wavefront, the trajectories
     // those two dropped and listed in `defer` because they needed a long regularisation scan (such scans run one
     // after the other in a wavefront, and a launch takes as long as its slowest wavefront).
     int s_first, s_step, group, lanes, n_range;
+    // The first two of those launches are one: workgroups 0 .. back_blocks - 1 take the `back_group` slots counted down
+    // from the last one, `back_lanes` per wavefront and spread (they run longer and start first); the others take the
+    // front as described by the fields above.
+    int back_blocks, back_group, back_lanes;
     int spread;                // entry of lane l of wavefront b: l * wavefronts + b instead of b * lanes + l, so that
                                // neighbours in a list, which tend to be alike in how long they take, meet in no wavefront
     int32_t* defer;
@@ -243,10 +247,14 @@ __global__ __launch_bounds__(PIPE_WG, M::BACKWARD_WAVES) void pipe_backward_kern
 {
     __shared__ double lds[stage_lds_doubles<M::NDX, M::NU, TermsOf<M>::type::AUX, (EXACT && !DEFER) ? WIDE_PARK : 64>() +
                           (EXACT ? exact_lds_doubles<M::NDX, M::NU>() : 0)];
-    const int i0 = (EXACT && a.spread) ? (int)(threadIdx.x * gridDim.x + blockIdx.x) : (int)(blockIdx.x * a.lanes + threadIdx.x);
-    bool live = (int)threadIdx.x < a.lanes && i0 < a.group;
-    const int i1 = live ? i0 : a.group - 1;      // a lane without a trajectory shadows the last one and stores nothing
-    const int s = (EXACT && i1 >= a.n_range) ? a.defer[i1 - a.n_range] : a.s_first + a.s_step * i1;
+    const bool backs = EXACT && DEFER && (int)blockIdx.x < a.back_blocks;
+    const int blk = (EXACT && DEFER && !backs) ? (int)blockIdx.x - a.back_blocks : (int)blockIdx.x;
+    const int lanes = backs ? a.back_lanes : a.lanes, group = backs ? a.back_group : a.group;
+    const int i0 = backs ? (int)threadIdx.x * a.back_blocks + blk
+                         : (EXACT && a.spread) ? (int)(threadIdx.x * gridDim.x + blockIdx.x) : blk * lanes + (int)threadIdx.x;
+    bool live = (int)threadIdx.x < lanes && i0 < group;
+    const int i1 = live ? i0 : group - 1;      // a lane without a trajectory shadows the last one and stores nothing
+    const int s = backs ? (int)a.B - 1 - i1 : (EXACT && i1 >= a.n_range) ? a.defer[i1 - a.n_range] : a.s_first + a.s_step * i1;
     const int S = a.N - 1;
     bool need_ls = false, cont = false;
     const SlotId sid = slot_id(a.idA[s]);
