@@ -20,6 +20,11 @@
 namespace ilqr {
 namespace eig {
 
+#ifdef ILQR_DEBUG_COUNTERS
+// cycles of wavefronts in has_negative(): [0] loading, norm and scaling, [1] DGEBAL or its shortcut, [2] DGEHD2,
+// [3] DLAHQR, [4] calls, [5] calls in which some lane ran DGEBAL itself, [6] QR sweeps of the slowest lane, summed
+static __device__ unsigned long long g_eig_cycles[8];
+#endif
 constexpr double SAFMIN = 2.2250738585072014e-308;   // DLAMCH('S')
 constexpr double ULP = 2.220446049250313e-16;        // DLAMCH('P') = eps * base
 constexpr double EPS = 1.1102230246251565e-16;       // DLAMCH('E')
@@ -711,6 +716,16 @@ struct Lane {
     __device__ int has_negative() const
     {
 #pragma clang fp contract(off)
+#ifdef ILQR_DEBUG_COUNTERS
+        const bool dbg_lead = (__ffsll((long long)__ballot(true)) - 1) == (int)(threadIdx.x & 63);
+        unsigned long long dbg_t = __builtin_readcyclecounter();
+        auto dbg_lap = [&](int slot) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            if (dbg_lead) atomicAdd(&g_eig_cycles[slot], now - dbg_t);
+            dbg_t = now;
+        };
+        if (dbg_lead) atomicAdd(&g_eig_cycles[4], 1ull);
+#endif
         double anrm = 0.0;
         bool finite = true;
         for (int e = 0; e < W * W; ++e) {
@@ -724,14 +739,31 @@ struct Lane {
         if (anrm > 0.0 && anrm < smlnum) lascl(anrm, smlnum);
         else if (anrm > bignum) lascl(anrm, bignum);
         int ilo = 1, ihi = W;
-        if (!gebal_is_identity()) {
+#ifdef ILQR_DEBUG_COUNTERS
+        dbg_lap(0);
+#endif
+        const bool plain = gebal_is_identity();
+#ifdef ILQR_DEBUG_COUNTERS
+        if (__ballot(!plain) && dbg_lead) atomicAdd(&g_eig_cycles[5], 1ull);
+#endif
+        if (!plain) {
             if (!gebal(ilo, ihi)) return -1;
         }
+#ifdef ILQR_DEBUG_COUNTERS
+        dbg_lap(1);
+#endif
         gehd2(ilo, ihi);
+#ifdef ILQR_DEBUG_COUNTERS
+        dbg_lap(2);
+#endif
         bool neg = false;
         for (int i = 1; i <= ilo - 1; ++i) neg = neg || (A(i, i) < 0.0);
         for (int i = ihi + 1; i <= W; ++i) neg = neg || (A(i, i) < 0.0);
-        if (!lahqr(ilo, ihi, neg)) return -1;
+        const bool conv = lahqr(ilo, ihi, neg);
+#ifdef ILQR_DEBUG_COUNTERS
+        dbg_lap(3);
+#endif
+        if (!conv) return -1;
         return neg ? 1 : 0;
     }
 };

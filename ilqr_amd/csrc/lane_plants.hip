@@ -22,6 +22,15 @@ extern "C" int ilqr_debug_counters(unsigned long long* out16, int reset)
     }
     return 0;
 }
+extern "C" int ilqr_debug_eig_cycles(unsigned long long* out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(ilqr::eig::g_eig_cycles), sizeof(ilqr::eig::g_eig_cycles)) != hipSuccess) return -3;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ilqr::eig::g_eig_cycles), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
 extern "C" int ilqr_debug_histograms(unsigned long long* out32, int reset)
 {
     if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(ilqr::g_hist), sizeof(ilqr::g_hist)) != hipSuccess) return -3;

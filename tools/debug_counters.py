@@ -23,6 +23,8 @@ x0, u0 = bench.car_inputs(B, 1234)
 L = s.lib
 out = (C.c_ulonglong * 16)()
 hist = (C.c_ulonglong * 32)()
+eigc = (C.c_ulonglong * 8)()
+L.ilqr_debug_eig_cycles(eigc, 1)
 L.ilqr_debug_histograms(hist, 1)
 L.ilqr_debug_counters(out, 1)
 r = s.solve(x0, u0)
@@ -36,6 +38,11 @@ L.ilqr_debug_histograms(hist, 1)
 h = list(hist)
 print("launch for long loops, tests per trajectory-pass,        bins 0, 1, 2, <=4, <=8, ...:", h[:14])
 print("launch for long loops, stages by the round the loop stopped at, bins 0, 1, 2, <=4, <=8, ...:", h[16:30])
+L.ilqr_debug_eig_cycles(eigc, 1)
+e = list(eigc)
+calls = max(e[4], 1)
+print(f"LAPACK tests of a wavefront: {e[4]}, cycles each: load/scale {e[0] / calls:.0f}, DGEBAL {e[1] / calls:.0f} "
+      f"(run in full in {e[5] / calls:.3f} of the tests), DGEHD2 {e[2] / calls:.0f}, DLAHQR {e[3] / calls:.0f}")
 trips = max(v[4], 1)
 print(f"long loops: {v[12] / 1e6:.1f} Mcycles in total, {v[12] / trips:.0f} cycles per test of 64 matrices")
 print(f"passes of wavefronts: the two launches that drop long loops {v[6]} passes, {v[13] / max(v[6], 1):.0f} cycles each; the launch for long loops {v[7]} passes, "
