@@ -24,7 +24,12 @@ namespace eig {
 // cycles of wavefronts in has_negative(): [0] loading, norm and scaling, [1] DGEBAL or its shortcut, [2] DGEHD2,
 // [3] DLAHQR, [4] calls, [5] calls in which some lane ran DGEBAL itself, [6] QR sweeps of the slowest lane, summed
 static __device__ unsigned long long g_eig_cycles[8];
+// per matrix, summed over matrices: [0] matrices, [1] QR iterations, [2] trips of the deflation search, [3] trips of
+// the search for two small subdiagonals, [4] of those settled without divisions, [5] reflector steps of the sweeps;
+// [6] QR iterations of the matrix with the most in its wavefront's test, summed over tests
+static __device__ unsigned long long g_eig_trips[12];   // [8..11] cycles of the first lane: splits, shifts, search for m, sweep
 #endif
+constexpr int SWEEP_IN_REGISTERS = 8;                // largest order whose QR sweep moves rows and columns through registers
 constexpr double SAFMIN = 2.2250738585072014e-308;   // DLAMCH('S')
 constexpr double ULP = 2.220446049250313e-16;        // DLAMCH('P') = eps * base
 constexpr double EPS = 1.1102230246251565e-16;       // DLAMCH('E')
@@ -94,6 +99,36 @@ __device__ inline double nrm2(int n, const double* x, int stride)
     }
     if (!(hi > 0.0) || !(hi <= DBL_MAX)) return __builtin_sqrt(hi);
     // square root of hi + lo to extended precision, then to double
+    const double r = __builtin_sqrt(hi);
+    const double res = __builtin_fma(-r, r, hi) + lo;
+    double rl = res / (2.0 * r);
+    double rh = r;
+    round64(rh, rl);
+    return rh + rl;
+}
+
+// nrm2() for a vector of N < 8 entries held in registers (one accumulator, in order: the same operations)
+template <int N>
+__device__ __forceinline__ double nrm2_small(const double (&x)[N])
+{
+#pragma clang fp contract(off)
+    static_assert(N >= 1 && N < 8, "single-accumulator case of nrm2()");
+    if (N == 1) return __builtin_fabs(x[0]);
+    double hi = 0.0, lo = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double v = x[i];
+        double p = v * v, pe = __builtin_fma(v, v, -p);
+        round64(p, pe);
+        const double s = hi + p;
+        const double bb = s - hi;
+        const double err = (hi - (s - bb)) + (p - bb);
+        double l2 = err + (lo + pe);
+        double h2 = s;
+        round64(h2, l2);
+        hi = h2; lo = l2;
+    }
+    if (!(hi > 0.0) || !(hi <= DBL_MAX)) return __builtin_sqrt(hi);
     const double r = __builtin_sqrt(hi);
     const double res = __builtin_fma(-r, r, hi) + lo;
     double rl = res / (2.0 * r);
@@ -405,18 +440,187 @@ struct Lane {
         }
     }
 
-    // DGEHD2
-    __device__ void gehd2(int ilo, int ihi) const
+    // DGEHD2.  `left_only`: reflector ilo has been generated and applied from the right already (its vector is in
+    // place); alpha0, tau0 are its beta and tau.
+    __device__ void gehd2(int ilo, int ihi, bool left_only = false, double alpha0 = 0.0, double tau0 = 0.0) const
     {
         const int n = W;
         for (int i = ilo; i <= ihi - 1; ++i) {
             const int r2 = (i + 2 < n) ? i + 2 : n;
             double alpha = A(i + 1, i), tau;
-            larfg(ihi - i, alpha, pA(r2, i), ES, tau);
+            const bool resume = left_only && i == ilo;
+            if (resume) { alpha = alpha0; tau = tau0; }
+            else larfg(ihi - i, alpha, pA(r2, i), ES, tau);
             A(i + 1, i) = 1.0;
-            larf(false, ihi, ihi - i, pA(i + 1, i), tau, pA(1, i + 1));
+            if (!resume) larf(false, ihi, ihi - i, pA(i + 1, i), tau, pA(1, i + 1));
             larf(true, ihi - i, n - i, pA(i + 1, i), tau, pA(i + 1, i + 1));
             A(i + 1, i) = alpha;
+        }
+    }
+
+    // ---- DGEHD2 of the whole matrix (ilo = 1, ihi = W) with the matrix in registers, for W <= 8 ----
+    // R[r + c W], 0-based.  Reflector I0 (0-based) is done here when nothing about it depends on where zeros happen
+    // to sit: DLARF shortens its products to the last non-zero entry of v and the last non-zero row / column of C, and
+    // the order of summation in the products depends on those lengths, so a reflector whose v ends in a zero, whose C
+    // has a zero last row (from the right) or a zero last column (from the left), or whose beta needs DLARFG's
+    // rescaling, is left to the routines above, which continue from the matrix as it then is.  Same operations in the
+    // same order as larfg / gemv_n / gemv_t / the DGER loops for these sizes.
+    // state: 0 going on, 1 stopped before reflector `at`, 2 stopped before the left application of reflector `at`
+    template <int I0>
+    __device__ __forceinline__ void hess_step(double (&R)[W * W], int& state, int& at, double& alpha_s, double& tau_s) const
+    {
+#pragma clang fp contract(off)
+        constexpr int NV = W - 1 - I0;       // entries of [alpha; x] = rows I0 + 1 .. W - 1 of column I0
+        constexpr int C0 = I0 + 1;           // first row / column of the blocks the reflector is applied to
+        static_assert(NV >= 2, "reflectors with a non-empty x");
+        if (state != 0) return;
+        double alpha = R[C0 + I0 * W];
+        double x[NV - 1];
+#pragma unroll
+        for (int t = 0; t < NV - 1; ++t) x[t] = R[C0 + 1 + t + I0 * W];
+        const double xnorm = nrm2_small<NV - 1>(x);
+        if (xnorm == 0.0) return;            // tau = 0: H = I, nothing changes
+        const double beta = -sgn(lapy2(alpha, xnorm), alpha);
+        bool plain = !(__builtin_fabs(beta) < SAFMIN / EPS);
+        const double tau = (beta - alpha) / beta;
+        const double sc = 1.0 / (alpha - beta);
+        double v[NV];
+        v[0] = 1.0;
+#pragma unroll
+        for (int t = 0; t < NV - 1; ++t) v[1 + t] = x[t] * sc;
+        plain = plain && (tau != 0.0) && (v[NV - 1] != 0.0);
+        {
+            bool lastrow = false;            // from the right: C = A(0 .. W-1, C0 .. W-1), its last row
+#pragma unroll
+            for (int j = 0; j < NV; ++j) lastrow = lastrow || (R[(W - 1) + (C0 + j) * W] != 0.0);
+            plain = plain && lastrow;
+        }
+        if (!plain) { state = 1; at = I0; return; }
+#pragma unroll
+        for (int t = 0; t < NV - 1; ++t) R[C0 + 1 + t + I0 * W] = v[1 + t];
+        const double mt = -tau;
+        double wk[W];
+        // ---- C = C H from the right: work = C v (gemv_n with m = W rows, n = NV columns), then the rank-one update
+        {
+            constexpr int m1 = W & ~3, n4 = NV & ~3;
+#pragma unroll
+            for (int i = 0; i < m1; ++i) {
+                double yi = 0.0;
+#pragma unroll
+                for (int j = 0; j < n4; j += 4) {
+                    double t = R[i + (C0 + j + 1) * W] * v[j + 1];
+                    t = __builtin_fma(R[i + (C0 + j) * W], v[j], t);
+                    t = __builtin_fma(R[i + (C0 + j + 2) * W], v[j + 2], t);
+                    t = __builtin_fma(R[i + (C0 + j + 3) * W], v[j + 3], t);
+                    yi = yi + t;
+                }
+                int j = n4;
+                if (NV & 2) {
+                    yi = yi + __builtin_fma(R[i + (C0 + j) * W], v[j], R[i + (C0 + j + 1) * W] * v[j + 1]);
+                    j += 2;
+                }
+                if (NV & 1) yi = yi + R[i + (C0 + j) * W] * v[j];
+                wk[i] = yi;
+            }
+#pragma unroll
+            for (int i = m1; i < W; ++i) {
+                double t = 0.0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) t = __builtin_fma(R[i + (C0 + j) * W], v[j], t);
+                wk[i] = 0.0 + t;
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const double t = mt * v[j];
+#pragma unroll
+                for (int i = 0; i < W; ++i) R[i + (C0 + j) * W] = __builtin_fma(t, wk[i], R[i + (C0 + j) * W]);
+            }
+        }
+        // ---- C = H C from the left: C = A(C0 .. W-1, C0 .. W-1), NV x NV; its last column must not be zero
+        {
+            bool lastcol = false;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) lastcol = lastcol || (R[(C0 + i) + (W - 1) * W] != 0.0);
+            if (!lastcol) { state = 2; at = I0; alpha_s = beta; tau_s = tau; return; }
+            constexpr int m1 = NV & ~3, m3 = NV & 3, n4 = NV & ~3;
+            double y[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                double yj = 0.0;
+                if (m1) {
+                    double blk;
+                    if (j < n4) {
+                        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+                        for (int i = 0; i < m1; i += 4) {
+                            t0 = __builtin_fma(R[(C0 + i + 0) + (C0 + j) * W], v[i + 0], t0);
+                            t1 = __builtin_fma(R[(C0 + i + 1) + (C0 + j) * W], v[i + 1], t1);
+                            t2 = __builtin_fma(R[(C0 + i + 2) + (C0 + j) * W], v[i + 2], t2);
+                            t3 = __builtin_fma(R[(C0 + i + 3) + (C0 + j) * W], v[i + 3], t3);
+                        }
+                        blk = (t0 + t2) + (t1 + t3);
+                    } else if ((NV & 2) && j < n4 + 2) {
+                        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                        for (int i = 0; i < m1; i += 2) {
+                            t0 = t0 + R[(C0 + i) + (C0 + j) * W] * v[i];
+                            t1 = t1 + R[(C0 + i + 1) + (C0 + j) * W] * v[i + 1];
+                        }
+                        blk = t0 + t1;
+                    } else {
+                        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+                        for (int i = 0; i < m1; i += 4) {
+                            t0 = t0 + R[(C0 + i + 0) + (C0 + j) * W] * v[i + 0];
+                            t1 = t1 + R[(C0 + i + 1) + (C0 + j) * W] * v[i + 1];
+                            t2 = t2 + R[(C0 + i + 2) + (C0 + j) * W] * v[i + 2];
+                            t3 = t3 + R[(C0 + i + 3) + (C0 + j) * W] * v[i + 3];
+                        }
+                        blk = (t0 + t2) + (t1 + t3);
+                    }
+                    yj = yj + blk;
+                }
+                if (m3 == 1) yj = __builtin_fma(R[(C0 + m1) + (C0 + j) * W], v[m1], yj);
+                else if (m3 == 2)
+                    yj = yj + __builtin_fma(R[(C0 + m1) + (C0 + j) * W], v[m1], R[(C0 + m1 + 1) + (C0 + j) * W] * v[m1 + 1]);
+                else if (m3 == 3)
+                    yj = yj + __builtin_fma(R[(C0 + m1 + 2) + (C0 + j) * W], v[m1 + 2],
+                                            __builtin_fma(R[(C0 + m1) + (C0 + j) * W], v[m1], R[(C0 + m1 + 1) + (C0 + j) * W] * v[m1 + 1]));
+                y[j] = yj;
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const double t = mt * y[j];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) R[(C0 + i) + (C0 + j) * W] = __builtin_fma(t, v[i], R[(C0 + i) + (C0 + j) * W]);
+            }
+        }
+        R[C0 + I0 * W] = beta;
+    }
+    template <int I0>
+    __device__ __forceinline__ void hess_steps(double (&R)[W * W], int& state, int& at, double& alpha_s, double& tau_s) const
+    {
+        if constexpr (I0 <= W - 3) {
+            hess_step<I0>(R, state, at, alpha_s, tau_s);
+            hess_steps<I0 + 1>(R, state, at, alpha_s, tau_s);
+        }
+    }
+    // DGEHD2(1, W): in registers as far as the reflectors are plain, the rest by gehd2()
+    __device__ void gehd2_whole() const
+    {
+        if constexpr (W >= 3 && W <= 8) {
+            double R[W * W];
+#pragma unroll
+            for (int e = 0; e < W * W; ++e) R[e] = a[e * ES];
+            int state = 0, at = W - 2;
+            double alpha_s = 0.0, tau_s = 0.0;
+            hess_steps<0>(R, state, at, alpha_s, tau_s);
+#pragma unroll
+            for (int e = 0; e < W * W; ++e) a[e * ES] = R[e];
+            if (state == 1) gehd2(at + 1, W);
+            else if (state == 2) gehd2(at + 1, W, true, alpha_s, tau_s);
+        } else {
+            gehd2(1, W);
         }
     }
 
@@ -436,12 +640,34 @@ struct Lane {
         const int itmax = 30 * (nh > 10 ? nh : 10);
         int kdefl = 0;
         int i = ihi;
-        while (i >= ilo) {
-            int l = ilo;
-            bool converged = false;
-            for (int its = 0; its <= itmax; ++its) {
-                int k;
+#ifdef ILQR_DEBUG_COUNTERS
+        unsigned dq = 0, dd = 0, dm = 0, dc = 0, dk = 0;
+#endif
+        // DLAHQR's two nested loops (over the blocks that split off at the bottom, and over the QR iterations that make
+        // one split off) run here as ONE loop whose trip is: look for the places where the matrix has split, record
+        // every block that has (cheap, repeated until a block needs more work), then one QR iteration.  Per matrix the
+        // operations and their order are DLAHQR's; for the wavefront it means that all lanes make their QR iterations
+        // together, whichever block each is working on, instead of waiting block by block for the lane that needs
+        // the most iterations for its current one.
+        int l = ilo, its = 0;
+        bool active = true, failed = false;
+#ifdef ILQR_DEBUG_COUNTERS
+        unsigned long long dbg_t = __builtin_readcyclecounter(), dbg_acc[4] = {0, 0, 0, 0};
+        auto dbg_lap = [&](int slot) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            dbg_acc[slot] += now - dbg_t;
+            dbg_t = now;
+        };
+#endif
+        while (active) {
+            bool sweep = false;
+            int k = 0;
+            while (active && !sweep) {
+                if (its > itmax) { failed = true; active = false; break; }
                 for (k = i; k >= l + 1; --k) {       // look for a single small subdiagonal element
+#ifdef ILQR_DEBUG_COUNTERS
+                    dd += 1;
+#endif
                     const double hkk1 = __builtin_fabs(A(k, k - 1));
                     if (hkk1 <= smlnum) break;
                     const double hk1 = A(k - 1, k - 1), hk = A(k, k);
@@ -461,8 +687,32 @@ struct Lane {
                 }
                 l = k;
                 if (l > ilo) A(l, l - 1) = 0.0;
-                if (l >= i - 1) { converged = true; break; }
+                if (l >= i - 1) {        // one or two eigenvalues have split off
+                    if (l == i) {
+                        neg = neg || (A(i, i) < 0.0);
+                    } else {
+                        double r1r, r1i, r2r, r2i;
+                        lanv2(A(i - 1, i - 1), A(i - 1, i), A(i, i - 1), A(i, i), r1r, r1i, r2r, r2i);
+                        // complex numbers compare by real part, then by imaginary part
+                        neg = neg || (r1r < 0.0) || (r1r == 0.0 && r1i < 0.0) || (r2r < 0.0) || (r2r == 0.0 && r2i < 0.0);
+                    }
+                    kdefl = 0;
+                    i = l - 1;
+                    l = ilo;
+                    its = 0;
+                    if (i < ilo) active = false;
+                } else {
+                    sweep = true;
+                }
+            }
+#ifdef ILQR_DEBUG_COUNTERS
+            dbg_lap(0);
+#endif
+            if (sweep) {
                 kdefl += 1;
+#ifdef ILQR_DEBUG_COUNTERS
+                dq += 1;
+#endif
                 const int i1 = l, i2 = i;
                 double h11, h12, h21, h22;
                 if (kdefl % (2 * kexsh) == 0) {
@@ -494,10 +744,39 @@ struct Lane {
                         }
                     }
                 }
+#ifdef ILQR_DEBUG_COUNTERS
+                dbg_lap(1);
+#endif
                 double v0 = 0.0, v1 = 0.0, v2 = 0.0;
                 int m;
                 for (m = i - 2; m >= l; --m) {        // look for two consecutive small subdiagonal elements
                     const double hmm = A(m, m), hm1m = A(m + 1, m);
+#ifdef ILQR_DEBUG_COUNTERS
+                    dm += 1;
+#endif
+                    if (m > l) {
+                        // Above the last m only the test at the end of this loop body matters, and it nearly always
+                        // fails by sixteen orders of magnitude.  Both of its sides carry the same positive factors
+                        // 1 / s, so it can be settled on the unscaled u = s * s' * v without the six divisions, as
+                        // long as the margin covers the rounding of u (e0, e1: bounds from the sizes of the terms
+                        // u0 and u1 are sums of): then this m is not the one, and v is not needed.
+                        const double a01 = A(m, m + 1), a11 = A(m + 1, m + 1), a21 = A(m + 2, m + 1);
+                        const double d1 = hmm - rt1r, d2 = hmm - rt2r;
+                        const double p0 = hm1m * a01, p1 = d1 * d2, p2 = rt1i * rt2i;
+                        const double u0 = (p0 + p1) - p2;
+                        const double e0 = 16.0 * ULP * (__builtin_fabs(p0) + __builtin_fabs(p1) + __builtin_fabs(p2));
+                        const double q1 = hmm + a11 - rt1r - rt2r;
+                        const double e1 = 16.0 * ULP * __builtin_fabs(hm1m) *
+                                          (__builtin_fabs(hmm) + __builtin_fabs(a11) + __builtin_fabs(rt1r) + __builtin_fabs(rt2r));
+                        const double lo = __builtin_fabs(A(m, m - 1)) *
+                                          ((__builtin_fabs(hm1m * q1) - e1) + __builtin_fabs(hm1m * a21));
+                        const double hi = ulp * (__builtin_fabs(u0) + e0) *
+                                          (__builtin_fabs(A(m - 1, m - 1)) + __builtin_fabs(hmm) + __builtin_fabs(a11));
+#ifdef ILQR_DEBUG_COUNTERS
+                        if (lo > 4.0 * hi && lo < 1e290 && hi > 1e-290) dc += 1;
+#endif
+                        if (lo > 4.0 * hi && lo < 1e290 && hi > 1e-290) continue;
+                    }
                     double h21s = __builtin_fabs(hm1m);
                     double s = __builtin_fabs(hmm - rt2r) + __builtin_fabs(rt2i) + h21s;
                     h21s = hm1m / s;
@@ -513,8 +792,14 @@ struct Lane {
                         ulp * __builtin_fabs(v0) * (h00 + h11a + h22a))
                         break;
                 }
+#ifdef ILQR_DEBUG_COUNTERS
+                dbg_lap(2);
+#endif
                 for (k = m; k <= i - 1; ++k) {        // double-shift QR step
                     const int nr = (3 < i - k + 1) ? 3 : i - k + 1;
+#ifdef ILQR_DEBUG_COUNTERS
+                    dk += 1;
+#endif
                     if (k > m) {
                         v0 = A(k, k - 1); v1 = A(k + 1, k - 1);
                         if (nr == 3) v2 = A(k + 2, k - 1);
@@ -534,6 +819,73 @@ struct Lane {
                         A(k, k - 1) = A(k, k - 1) * (1.0 - t1);
                     }
                     const double t2 = t1 * v1;
+                    if constexpr (W <= SWEEP_IN_REGISTERS) {
+                        // The same updates with the three rows, then the three columns, moved through registers in one
+                        // go: every entry of rows k .. k+2 (columns k .. k+2) is read, the ones in range are updated,
+                        // all are written back; with two rows (nr == 2) the third is read and left alone.  (Row or
+                        // column W + 1 of such a read is the lane's work space.)
+                        const bool nr3 = (nr == 3);
+                        const double t3 = nr3 ? t1 * v2 : 0.0;
+                        {
+                            double* const rowk = a + (k - 1) * ES;
+                            double r0[W], r1[W], r2[W];
+#pragma unroll
+                            for (int j = 0; j < W; ++j) {
+                                r0[j] = rowk[(j * W) * ES];
+                                r1[j] = rowk[(j * W + 1) * ES];
+                                r2[j] = rowk[(j * W + 2) * ES];
+                            }
+#pragma unroll
+                            for (int j = 0; j < W; ++j) {
+                                const bool on = (j + 1 >= k) && (j + 1 <= i2);
+                                const double p = r0[j] + v1 * r1[j];
+                                const double sum = nr3 ? p + v2 * r2[j] : p;
+                                const double n0 = r0[j] - sum * t1, n1 = r1[j] - sum * t2, n2 = r2[j] - sum * t3;
+                                r0[j] = on ? n0 : r0[j];
+                                r1[j] = on ? n1 : r1[j];
+                                r2[j] = on ? n2 : r2[j];
+                            }
+#pragma unroll
+                            for (int j = 0; j < W; ++j) {
+                                rowk[(j * W) * ES] = r0[j];
+                                rowk[(j * W + 1) * ES] = r1[j];
+                            }
+                            if (nr3) {
+#pragma unroll
+                                for (int j = 0; j < W; ++j) rowk[(j * W + 2) * ES] = r2[j];
+                            }
+                        }
+                        {
+                            const int jend = (k + 3 < i) ? k + 3 : i;
+                            double* const colk = a + ((k - 1) * W) * ES;
+                            double c0[W], c1[W], c2[W];
+#pragma unroll
+                            for (int r = 0; r < W; ++r) {
+                                c0[r] = colk[r * ES];
+                                c1[r] = colk[(r + W) * ES];
+                                c2[r] = colk[(r + 2 * W) * ES];
+                            }
+#pragma unroll
+                            for (int r = 0; r < W; ++r) {
+                                const bool on = (r + 1 >= i1) && (r + 1 <= jend);
+                                const double p = c0[r] + v1 * c1[r];
+                                const double sum = nr3 ? p + v2 * c2[r] : p;
+                                const double n0 = c0[r] - sum * t1, n1 = c1[r] - sum * t2, n2 = c2[r] - sum * t3;
+                                c0[r] = on ? n0 : c0[r];
+                                c1[r] = on ? n1 : c1[r];
+                                c2[r] = on ? n2 : c2[r];
+                            }
+#pragma unroll
+                            for (int r = 0; r < W; ++r) {
+                                colk[r * ES] = c0[r];
+                                colk[(r + W) * ES] = c1[r];
+                            }
+                            if (nr3) {
+#pragma unroll
+                                for (int r = 0; r < W; ++r) colk[(r + 2 * W) * ES] = c2[r];
+                            }
+                        }
+                    } else
                     if (nr == 3) {
                         const double t3 = t1 * v2;
                         for (int j = k; j <= i2; ++j) {
@@ -566,20 +918,27 @@ struct Lane {
                         }
                     }
                 }
+                its += 1;
+#ifdef ILQR_DEBUG_COUNTERS
+                dbg_lap(3);
+#endif
             }
-            if (!converged) return false;
-            if (l == i) {
-                neg = neg || (A(i, i) < 0.0);
-            } else {
-                double r1r, r1i, r2r, r2i;
-                lanv2(A(i - 1, i - 1), A(i - 1, i), A(i, i - 1), A(i, i), r1r, r1i, r2r, r2i);
-                // complex numbers compare by real part, then by imaginary part
-                neg = neg || (r1r < 0.0) || (r1r == 0.0 && r1i < 0.0) || (r2r < 0.0) || (r2r == 0.0 && r2i < 0.0);
-            }
-            kdefl = 0;
-            i = l - 1;
         }
-        return true;
+#ifdef ILQR_DEBUG_COUNTERS
+        if ((__ffsll((long long)__ballot(true)) - 1) == (int)(threadIdx.x & 63))
+            for (int q = 0; q < 4; ++q) atomicAdd(&g_eig_trips[8 + q], dbg_acc[q]);
+#endif
+#ifdef ILQR_DEBUG_COUNTERS
+        atomicAdd(&g_eig_trips[0], 1ull); atomicAdd(&g_eig_trips[1], (unsigned long long)dq);
+        atomicAdd(&g_eig_trips[2], (unsigned long long)dd); atomicAdd(&g_eig_trips[3], (unsigned long long)dm);
+        atomicAdd(&g_eig_trips[4], (unsigned long long)dc); atomicAdd(&g_eig_trips[5], (unsigned long long)dk);
+        {
+            unsigned mxq = dq;
+            for (int d = 32; d >= 1; d /= 2) { const unsigned o = __shfl_xor(mxq, d); mxq = o > mxq ? o : mxq; }
+            if ((__ffsll((long long)__ballot(true)) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&g_eig_trips[6], (unsigned long long)mxq);
+        }
+#endif
+        return !failed;
     }
 
     // DLARFG for the 2- and 3-vectors of the QR sweep, tail in registers
@@ -589,8 +948,8 @@ struct Lane {
         double xnorm;
         if (n == 2) xnorm = __builtin_fabs(x[0]);
         else {
-            double t[2] = {x[0], x[1]};
-            xnorm = nrm2(2, t, 1);
+            const double t[2] = {x[0], x[1]};
+            xnorm = nrm2_small<2>(t);
         }
         if (n <= 1 || xnorm == 0.0) { tau = 0.0; return; }
         double beta = -sgn(lapy2(alpha, xnorm), alpha);
@@ -607,8 +966,8 @@ struct Lane {
             } while (__builtin_fabs(beta) < safmin && knt < 20);
             if (n == 2) xnorm = __builtin_fabs(x[0]);
             else {
-                double t[2] = {x[0], x[1]};
-                xnorm = nrm2(2, t, 1);
+                const double t[2] = {x[0], x[1]};
+                xnorm = nrm2_small<2>(t);
             }
             beta = -sgn(lapy2(alpha, xnorm), alpha);
         }
@@ -752,7 +1111,8 @@ struct Lane {
 #ifdef ILQR_DEBUG_COUNTERS
         dbg_lap(1);
 #endif
-        gehd2(ilo, ihi);
+        if (ilo == 1 && ihi == W) gehd2_whole();
+        else gehd2(ilo, ihi);
 #ifdef ILQR_DEBUG_COUNTERS
         dbg_lap(2);
 #endif

@@ -31,6 +31,15 @@ extern "C" int ilqr_debug_eig_cycles(unsigned long long* out8, int reset)
     }
     return 0;
 }
+extern "C" int ilqr_debug_eig_trips(unsigned long long* out12, int reset)
+{
+    if (out12 && hipMemcpyFromSymbol(out12, HIP_SYMBOL(ilqr::eig::g_eig_trips), sizeof(ilqr::eig::g_eig_trips)) != hipSuccess) return -3;
+    if (reset) {
+        unsigned long long z[12] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ilqr::eig::g_eig_trips), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
 extern "C" int ilqr_debug_histograms(unsigned long long* out32, int reset)
 {
     if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(ilqr::g_hist), sizeof(ilqr::g_hist)) != hipSuccess) return -3;

@@ -24,7 +24,9 @@ L = s.lib
 out = (C.c_ulonglong * 16)()
 hist = (C.c_ulonglong * 32)()
 eigc = (C.c_ulonglong * 8)()
+eigt = (C.c_ulonglong * 12)()
 L.ilqr_debug_eig_cycles(eigc, 1)
+L.ilqr_debug_eig_trips(eigt, 1)
 L.ilqr_debug_histograms(hist, 1)
 L.ilqr_debug_counters(out, 1)
 r = s.solve(x0, u0)
@@ -43,6 +45,14 @@ e = list(eigc)
 calls = max(e[4], 1)
 print(f"LAPACK tests of a wavefront: {e[4]}, cycles each: load/scale {e[0] / calls:.0f}, DGEBAL {e[1] / calls:.0f} "
       f"(run in full in {e[5] / calls:.3f} of the tests), DGEHD2 {e[2] / calls:.0f}, DLAHQR {e[3] / calls:.0f}")
+L.ilqr_debug_eig_trips(eigt, 1)
+t = list(eigt)
+nm = max(t[0], 1)
+print(f"per matrix on LAPACK's path ({t[0]} matrices): QR iterations {t[1] / nm:.1f}, deflation-search trips {t[2] / nm:.1f}, "
+      f"trips of the search for two small subdiagonals {t[3] / nm:.1f} ({t[4] / nm:.1f} settled without divisions), reflector steps "
+      f"{t[5] / nm:.1f}; QR iterations of the slowest matrix of a test {t[6] / calls:.1f}")
+print(f"DLAHQR cycles per test (first lane's clock): splits {t[8] / calls:.0f}, shifts {t[9] / calls:.0f}, search for two small "
+      f"subdiagonals {t[10] / calls:.0f}, sweep {t[11] / calls:.0f}")
 trips = max(v[4], 1)
 print(f"long loops: {v[12] / 1e6:.1f} Mcycles in total, {v[12] / trips:.0f} cycles per test of 64 matrices")
 print(f"passes of wavefronts: the two launches that drop long loops {v[6]} passes, {v[13] / max(v[6], 1):.0f} cycles each; the launch for long loops {v[7]} passes, "
