@@ -25,11 +25,10 @@ namespace eig {
 // [3] DLAHQR, [4] calls, [5] calls in which some lane ran DGEBAL itself, [6] QR sweeps of the slowest lane, summed
 static __device__ unsigned long long g_eig_cycles[8];
 // per matrix, summed over matrices: [0] matrices, [1] QR iterations, [2] trips of the deflation search, [3] trips of
-// the search for two small subdiagonals, [4] of those settled without divisions, [5] reflector steps of the sweeps;
+// the search for two small subdiagonals, [5] reflector steps of the sweeps;
 // [6] QR iterations of the matrix with the most in its wavefront's test, summed over tests
 static __device__ unsigned long long g_eig_trips[12];   // [8..11] cycles of the first lane: splits, shifts, search for m, sweep
 #endif
-constexpr int SWEEP_IN_REGISTERS = 8;                // largest order whose QR sweep moves rows and columns through registers
 constexpr double SAFMIN = 2.2250738585072014e-308;   // DLAMCH('S')
 constexpr double ULP = 2.220446049250313e-16;        // DLAMCH('P') = eps * base
 constexpr double EPS = 1.1102230246251565e-16;       // DLAMCH('E')
@@ -641,7 +640,7 @@ struct Lane {
         int kdefl = 0;
         int i = ihi;
 #ifdef ILQR_DEBUG_COUNTERS
-        unsigned dq = 0, dd = 0, dm = 0, dc = 0, dk = 0;
+        unsigned dq = 0, dd = 0, dm = 0, dk = 0;
 #endif
         // DLAHQR's two nested loops (over the blocks that split off at the bottom, and over the QR iterations that make
         // one split off) run here as ONE loop whose trip is: look for the places where the matrix has split, record
@@ -754,29 +753,6 @@ struct Lane {
 #ifdef ILQR_DEBUG_COUNTERS
                     dm += 1;
 #endif
-                    if (m > l) {
-                        // Above the last m only the test at the end of this loop body matters, and it nearly always
-                        // fails by sixteen orders of magnitude.  Both of its sides carry the same positive factors
-                        // 1 / s, so it can be settled on the unscaled u = s * s' * v without the six divisions, as
-                        // long as the margin covers the rounding of u (e0, e1: bounds from the sizes of the terms
-                        // u0 and u1 are sums of): then this m is not the one, and v is not needed.
-                        const double a01 = A(m, m + 1), a11 = A(m + 1, m + 1), a21 = A(m + 2, m + 1);
-                        const double d1 = hmm - rt1r, d2 = hmm - rt2r;
-                        const double p0 = hm1m * a01, p1 = d1 * d2, p2 = rt1i * rt2i;
-                        const double u0 = (p0 + p1) - p2;
-                        const double e0 = 16.0 * ULP * (__builtin_fabs(p0) + __builtin_fabs(p1) + __builtin_fabs(p2));
-                        const double q1 = hmm + a11 - rt1r - rt2r;
-                        const double e1 = 16.0 * ULP * __builtin_fabs(hm1m) *
-                                          (__builtin_fabs(hmm) + __builtin_fabs(a11) + __builtin_fabs(rt1r) + __builtin_fabs(rt2r));
-                        const double lo = __builtin_fabs(A(m, m - 1)) *
-                                          ((__builtin_fabs(hm1m * q1) - e1) + __builtin_fabs(hm1m * a21));
-                        const double hi = ulp * (__builtin_fabs(u0) + e0) *
-                                          (__builtin_fabs(A(m - 1, m - 1)) + __builtin_fabs(hmm) + __builtin_fabs(a11));
-#ifdef ILQR_DEBUG_COUNTERS
-                        if (lo > 4.0 * hi && lo < 1e290 && hi > 1e-290) dc += 1;
-#endif
-                        if (lo > 4.0 * hi && lo < 1e290 && hi > 1e-290) continue;
-                    }
                     double h21s = __builtin_fabs(hm1m);
                     double s = __builtin_fabs(hmm - rt2r) + __builtin_fabs(rt2i) + h21s;
                     h21s = hm1m / s;
@@ -819,73 +795,6 @@ struct Lane {
                         A(k, k - 1) = A(k, k - 1) * (1.0 - t1);
                     }
                     const double t2 = t1 * v1;
-                    if constexpr (W <= SWEEP_IN_REGISTERS) {
-                        // The same updates with the three rows, then the three columns, moved through registers in one
-                        // go: every entry of rows k .. k+2 (columns k .. k+2) is read, the ones in range are updated,
-                        // all are written back; with two rows (nr == 2) the third is read and left alone.  (Row or
-                        // column W + 1 of such a read is the lane's work space.)
-                        const bool nr3 = (nr == 3);
-                        const double t3 = nr3 ? t1 * v2 : 0.0;
-                        {
-                            double* const rowk = a + (k - 1) * ES;
-                            double r0[W], r1[W], r2[W];
-#pragma unroll
-                            for (int j = 0; j < W; ++j) {
-                                r0[j] = rowk[(j * W) * ES];
-                                r1[j] = rowk[(j * W + 1) * ES];
-                                r2[j] = rowk[(j * W + 2) * ES];
-                            }
-#pragma unroll
-                            for (int j = 0; j < W; ++j) {
-                                const bool on = (j + 1 >= k) && (j + 1 <= i2);
-                                const double p = r0[j] + v1 * r1[j];
-                                const double sum = nr3 ? p + v2 * r2[j] : p;
-                                const double n0 = r0[j] - sum * t1, n1 = r1[j] - sum * t2, n2 = r2[j] - sum * t3;
-                                r0[j] = on ? n0 : r0[j];
-                                r1[j] = on ? n1 : r1[j];
-                                r2[j] = on ? n2 : r2[j];
-                            }
-#pragma unroll
-                            for (int j = 0; j < W; ++j) {
-                                rowk[(j * W) * ES] = r0[j];
-                                rowk[(j * W + 1) * ES] = r1[j];
-                            }
-                            if (nr3) {
-#pragma unroll
-                                for (int j = 0; j < W; ++j) rowk[(j * W + 2) * ES] = r2[j];
-                            }
-                        }
-                        {
-                            const int jend = (k + 3 < i) ? k + 3 : i;
-                            double* const colk = a + ((k - 1) * W) * ES;
-                            double c0[W], c1[W], c2[W];
-#pragma unroll
-                            for (int r = 0; r < W; ++r) {
-                                c0[r] = colk[r * ES];
-                                c1[r] = colk[(r + W) * ES];
-                                c2[r] = colk[(r + 2 * W) * ES];
-                            }
-#pragma unroll
-                            for (int r = 0; r < W; ++r) {
-                                const bool on = (r + 1 >= i1) && (r + 1 <= jend);
-                                const double p = c0[r] + v1 * c1[r];
-                                const double sum = nr3 ? p + v2 * c2[r] : p;
-                                const double n0 = c0[r] - sum * t1, n1 = c1[r] - sum * t2, n2 = c2[r] - sum * t3;
-                                c0[r] = on ? n0 : c0[r];
-                                c1[r] = on ? n1 : c1[r];
-                                c2[r] = on ? n2 : c2[r];
-                            }
-#pragma unroll
-                            for (int r = 0; r < W; ++r) {
-                                colk[r * ES] = c0[r];
-                                colk[(r + W) * ES] = c1[r];
-                            }
-                            if (nr3) {
-#pragma unroll
-                                for (int r = 0; r < W; ++r) colk[(r + 2 * W) * ES] = c2[r];
-                            }
-                        }
-                    } else
                     if (nr == 3) {
                         const double t3 = t1 * v2;
                         for (int j = k; j <= i2; ++j) {
@@ -931,7 +840,7 @@ struct Lane {
 #ifdef ILQR_DEBUG_COUNTERS
         atomicAdd(&g_eig_trips[0], 1ull); atomicAdd(&g_eig_trips[1], (unsigned long long)dq);
         atomicAdd(&g_eig_trips[2], (unsigned long long)dd); atomicAdd(&g_eig_trips[3], (unsigned long long)dm);
-        atomicAdd(&g_eig_trips[4], (unsigned long long)dc); atomicAdd(&g_eig_trips[5], (unsigned long long)dk);
+        atomicAdd(&g_eig_trips[5], (unsigned long long)dk);
         {
             unsigned mxq = dq;
             for (int d = 32; d >= 1; d /= 2) { const unsigned o = __shfl_xor(mxq, d); mxq = o > mxq ? o : mxq; }

@@ -49,7 +49,7 @@ L.ilqr_debug_eig_trips(eigt, 1)
 t = list(eigt)
 nm = max(t[0], 1)
 print(f"per matrix on LAPACK's path ({t[0]} matrices): QR iterations {t[1] / nm:.1f}, deflation-search trips {t[2] / nm:.1f}, "
-      f"trips of the search for two small subdiagonals {t[3] / nm:.1f} ({t[4] / nm:.1f} settled without divisions), reflector steps "
+      f"trips of the search for two small subdiagonals {t[3] / nm:.1f}, reflector steps "
       f"{t[5] / nm:.1f}; QR iterations of the slowest matrix of a test {t[6] / calls:.1f}")
 print(f"DLAHQR cycles per test (first lane's clock): splits {t[8] / calls:.0f}, shifts {t[9] / calls:.0f}, search for two small "
       f"subdiagonals {t[10] / calls:.0f}, sweep {t[11] / calls:.0f}")
