@@ -56,3 +56,34 @@ def test_device_rule_against_numpy_on_random_matrices():
     bad = np.eye(7)[None].repeat(3, 0).copy()
     bad[0, 2, 3] = np.nan; bad[1, 0, 0] = np.inf
     assert gpu_verdicts(bad).tolist() == [-1, -1, 0]
+
+
+def test_device_rule_on_matrices_whose_reflectors_are_not_plain():
+    """Zero patterns that keep DGEBAL a no-op but shorten DLARF's products (a Householder vector that ends in zeros, a
+    block with a zero last row, matrices that are Hessenberg or triangular already): the orders 3..8 reduce such a
+    reflector with the general routines instead of the register version, and the verdicts stay NumPy's."""
+    rng = np.random.default_rng(77)
+    for n in (3, 4, 5, 6, 7, 8):
+        mats = []
+        for t in range(1200):
+            A = rng.standard_normal((n, n)) + (t % 3 - 1) * 0.5 * np.eye(n)
+            kind = t % 6
+            if kind == 0:
+                A[n - 1, 0] = 0.0                       # first reflector's vector ends in a zero
+            elif kind == 1 and n >= 4:
+                A[n - 2:, 0] = 0.0; A[n - 1, 1] = 0.0   # ... in two zeros, and the second one's in one
+            elif kind == 2:
+                A[n - 1, 1:] = 0.0; A[n - 1, 0] = 1.5   # the block the first reflector is applied to has a zero last row
+            elif kind == 3:
+                A = np.triu(A, -1)                      # Hessenberg already: every x is zero
+            elif kind == 4:
+                A = np.triu(A); A[n - 1, 0] = 0.3       # triangular but for one corner entry
+            else:
+                A[2:, 0] = 0.0; A[3:, 1] = 0.0          # the first two columns reduced already
+            mats.append(A)
+        mats = np.stack(mats)
+        with np.errstate(all="ignore"):
+            want = np.array([bool(np.any(np.linalg.eigvals(m) < 0)) for m in mats], dtype=np.int32)
+        got = gpu_verdicts(mats)
+        wrong = np.where(got != want)[0]
+        assert len(wrong) <= 2, (n, len(wrong), wrong[:10])
