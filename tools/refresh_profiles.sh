@@ -1,6 +1,8 @@
 #!/bin/bash
 # Regenerates the files under profiles/ on the GPU box: tools/refresh_profiles.sh <tag>   (e.g. r01)
 # Run from the repository root through gpurun; every GPU step has its own time limit.
+# Afterwards, here: copy gpurun_out/prof_<tag>/* to profiles/<tag>_*, and hbm_traffic.json ALSO to
+# profiles/traffic_latest.json (bench.py reports traffic only from a file whose library_fingerprint matches its library).
 set -e
 tag=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$PWD}
