@@ -44,6 +44,19 @@ def test_outputs_do_not_depend_on_the_batch_a_trajectory_is_in(torch_gpu):
         _same(whole, part, idx, f"group {gi}")
 
 
+@pytest.mark.parametrize("N,max_iter", [(2, 50), (3, 50), (40, 1), (40, 3), (12, 50)])
+def test_small_and_ragged_batches(torch_gpu, N, max_iter):
+    """Batches of 1, 3, 65 and 130 trajectories (launches with a single, partly filled wavefront per range), the
+    shortest horizons and cut-off iteration counts: the same bits as the same trajectories inside a batch of 1 000."""
+    import bench
+    x0, u0 = bench.car_inputs(1000, 7, N)
+    x0[::7] *= 3.0                      # some far starts, so that long loops occur at short horizons too
+    whole = _solve(x0, u0, N, max_iter)
+    for idx in (np.arange(1), np.arange(5, 8), np.arange(100, 165), np.arange(300, 430)):
+        part = _solve(x0[idx], u0[idx], N, max_iter)
+        _same(whole, part, idx, f"N {N} max_iter {max_iter} batch {len(idx)}")
+
+
 def test_outputs_do_not_depend_on_how_wavefronts_are_packed(torch_gpu):
     import bench
     B = 16384
