@@ -356,79 +356,83 @@ def main():
                          "phase_ms": {k: v[0] for k, v in phases.items() if k != "iterations"},
                          "phase_launches": {k: v[1] for k, v in phases.items() if k != "iterations"}},
         }
-        # ---- parity spot check and CPU baseline (rank 0, N=1 only for the baseline) ----
-        if a.check or (a.cpu_sample and world == 1):
-            from oracle import c_oracle as co
-            co.build()
-            cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
-            par = co.pack_car(2.0, 2.0)
-            if a.check:
-                # The first c trajectories against the CPU checker.  Which solves CAN be compared one by one is decided
-                # the way the fixtures under tests/golden decide it: the checker solves them a second time with every
-                # input changed in its 14th digit, and a solve counts as reproducible if both runs take the same
-                # decisions and end within 1e-8 of each other (ill-conditioned solves amplify rounding differences
-                # until they do not; those are compared as a population by the tests, not here).
-                c = min(a.check, B)
-                rng = np.random.default_rng(99)
-                ref = co.solve_batch("car", par, N, 50, 20, 1e-3, x0_np[:c], u0_np[:c], nthreads=cores)
-                ref2 = co.solve_batch("car", par, N, 50, 20, 1e-3,
-                                      x0_np[:c] * (1.0 + 1e-14 * rng.choice([-1.0, 1.0], size=x0_np[:c].shape)),
-                                      u0_np[:c] * (1.0 + 1e-14 * rng.choice([-1.0, 1.0], size=u0_np[:c].shape)), nthreads=cores)
-                i1, i2 = ref["info"], ref2["info"]
-                scale = np.abs(ref["x"]).reshape(c, -1).max(1)
-                with np.errstate(invalid="ignore"):
-                    drift = np.abs(ref["x"] - ref2["x"]).reshape(c, -1).max(1) / scale
-                repro = ((i1["iters"] == i2["iters"]) & (i1["status"] == i2["status"]) & (i1["ls_total"] == i2["ls_total"])
-                         & (i1["regu_rounds"] == i2["regu_rounds"]) & (drift <= 1e-8))
-                it = out["iters"][:c].cpu().numpy()
-                st = out["status"][:c].cpu().numpy()
-                same = (it == i1["iters"]) & (st == i1["status"])
-                xg = x[:, :, :c].permute(2, 0, 1).cpu().numpy()
-                with np.errstate(invalid="ignore"):
-                    err = np.abs(xg - ref["x"]).reshape(c, -1).max(1) / scale
-                sel = err[repro & same] if (repro & same).any() else np.array([np.nan])
-                # the bar of the tests (tests/helpers.py): 1e-8, or 100 times what the checker's own answer moves under
-                # the 1e-14 perturbation where that is more
-                bar = np.maximum(1e-8, 100.0 * drift)[repro & same] if (repro & same).any() else np.array([np.nan])
-                calm = i1["max_abs_q"] < 1e5
-                # the reproducible solves that are NOT within 1e-8, one by one
-                idx = np.where(repro & same)[0]
-                beyond = [dict(index=int(b), rel_x_err=float(err[b]), checker_own_drift=float(drift[b]),
-                               exit=co.EXIT_NAMES[int(st[b])], iters=int(it[b]), max_abs_q=float(i1["max_abs_q"][b]))
-                          for b in idx[err[idx] > 1e-8][:16]]
-                res["parity_check"] = {"beyond_1e-8": beyond,"checked": int(c), "reproducible": int(repro.sum()),
-                                       "reproducible_same_decisions": int((repro & same).sum()),
-                                       "max_rel_x_err_reproducible": float(np.nanmax(sel)),
-                                       "median_rel_x_err_reproducible": float(np.nanmedian(sel)),
-                                       "frac_rel_x_err_le_1e-8_reproducible": float((sel <= 1e-8).mean()),
-                                       "frac_within_parity_bar_reproducible": float((sel <= bar).mean()),
-                                       "all_same_iters_and_exit": int(same.sum()),
-                                       "max_abs_q_below_1e5": int(calm.sum()),
-                                       "max_abs_q_below_1e5_same_decisions": int((calm & same).sum()),
-                                       "note": "reproducible = the CPU checker repeats its own decisions and ends within 1e-8 when "
-                                               "its inputs are changed in the 14th digit"}
-            if a.cpu_sample and world == 1:
-                c = min(a.cpu_sample, B)
-                t1 = time.perf_counter()
-                co.solve_batch("car", par, N, 50, 20, 1e-3, x0_np[:c], u0_np[:c], nthreads=cores, rule="lapack")
-                dt = time.perf_counter() - t1
-                t1 = time.perf_counter()
-                co.solve_batch("car", par, N, 50, 20, 1e-3, x0_np[:c], u0_np[:c], nthreads=cores, rule="ldl")
-                dt2 = time.perf_counter() - t1
-                res["cpu_baseline"] = {"value": c / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-                                       "rule": "lapack",
-                                       "rule_note": "np.linalg.eigvals restated (DGEEV): the reference's own test, the "
-                                                    "partner of the `faithful` record; the headline `value` runs the "
-                                                    "kernels' default LDL' test, whose CPU partner is `ldl`",
-                                       "sample": f"first {c} trajectories of the same batch, C restatement of the "
-                                                 f"reference solver (oracle/), OpenMP over {cores} threads, {dt:.1f} s",
-                                       "ldl": {"value": c / dt2, "unit": "solves/s", "rule": "ldl",
-                                               "sample": f"the same {c} trajectories with the kernels' LDL' rule, {dt2:.1f} s"}}
-        if world == 1 and a.faithful_batch != 0 and not a.lapack_eigvals:
-            fb = B if a.faithful_batch < 0 else min(a.faithful_batch, B)
-            res["faithful"] = faithful_record(dev, (0, [2.0, 2.0], N, 50, 20, 1e-3), x0[:, :fb].contiguous(),
-                                              u_init[:, :, :fb].contiguous(), N, 1)
-            res["faithful"]["vs_headline"] = res["faithful"]["value"] / value
+        # (whatever goes wrong in the additions below, the line with the timed result is still printed)
+        try:
+            # ---- parity spot check and CPU baseline (rank 0, N=1 only for the baseline) ----
+            if a.check or (a.cpu_sample and world == 1):
+                from oracle import c_oracle as co
+                co.build()
+                cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+                par = co.pack_car(2.0, 2.0)
+                if a.check:
+                    # The first c trajectories against the CPU checker.  Which solves CAN be compared one by one is decided
+                    # the way the fixtures under tests/golden decide it: the checker solves them a second time with every
+                    # input changed in its 14th digit, and a solve counts as reproducible if both runs take the same
+                    # decisions and end within 1e-8 of each other (ill-conditioned solves amplify rounding differences
+                    # until they do not; those are compared as a population by the tests, not here).
+                    c = min(a.check, B)
+                    rng = np.random.default_rng(99)
+                    ref = co.solve_batch("car", par, N, 50, 20, 1e-3, x0_np[:c], u0_np[:c], nthreads=cores)
+                    ref2 = co.solve_batch("car", par, N, 50, 20, 1e-3,
+                                          x0_np[:c] * (1.0 + 1e-14 * rng.choice([-1.0, 1.0], size=x0_np[:c].shape)),
+                                          u0_np[:c] * (1.0 + 1e-14 * rng.choice([-1.0, 1.0], size=u0_np[:c].shape)), nthreads=cores)
+                    i1, i2 = ref["info"], ref2["info"]
+                    scale = np.abs(ref["x"]).reshape(c, -1).max(1)
+                    with np.errstate(invalid="ignore"):
+                        drift = np.abs(ref["x"] - ref2["x"]).reshape(c, -1).max(1) / scale
+                    repro = ((i1["iters"] == i2["iters"]) & (i1["status"] == i2["status"]) & (i1["ls_total"] == i2["ls_total"])
+                             & (i1["regu_rounds"] == i2["regu_rounds"]) & (drift <= 1e-8))
+                    it = out["iters"][:c].cpu().numpy()
+                    st = out["status"][:c].cpu().numpy()
+                    same = (it == i1["iters"]) & (st == i1["status"])
+                    xg = x[:, :, :c].permute(2, 0, 1).cpu().numpy()
+                    with np.errstate(invalid="ignore"):
+                        err = np.abs(xg - ref["x"]).reshape(c, -1).max(1) / scale
+                    sel = err[repro & same] if (repro & same).any() else np.array([np.nan])
+                    # the bar of the tests (tests/helpers.py): 1e-8, or 100 times what the checker's own answer moves under
+                    # the 1e-14 perturbation where that is more
+                    bar = np.maximum(1e-8, 100.0 * drift)[repro & same] if (repro & same).any() else np.array([np.nan])
+                    calm = i1["max_abs_q"] < 1e5
+                    # the reproducible solves that are NOT within 1e-8, one by one
+                    idx = np.where(repro & same)[0]
+                    beyond = [dict(index=int(b), rel_x_err=float(err[b]), checker_own_drift=float(drift[b]),
+                                   exit=co.EXIT_NAMES[int(st[b])], iters=int(it[b]), max_abs_q=float(i1["max_abs_q"][b]))
+                              for b in idx[err[idx] > 1e-8][:16]]
+                    res["parity_check"] = {"beyond_1e-8": beyond,"checked": int(c), "reproducible": int(repro.sum()),
+                                           "reproducible_same_decisions": int((repro & same).sum()),
+                                           "max_rel_x_err_reproducible": float(np.nanmax(sel)),
+                                           "median_rel_x_err_reproducible": float(np.nanmedian(sel)),
+                                           "frac_rel_x_err_le_1e-8_reproducible": float((sel <= 1e-8).mean()),
+                                           "frac_within_parity_bar_reproducible": float((sel <= bar).mean()),
+                                           "all_same_iters_and_exit": int(same.sum()),
+                                           "max_abs_q_below_1e5": int(calm.sum()),
+                                           "max_abs_q_below_1e5_same_decisions": int((calm & same).sum()),
+                                           "note": "reproducible = the CPU checker repeats its own decisions and ends within 1e-8 when "
+                                                   "its inputs are changed in the 14th digit"}
+                if a.cpu_sample and world == 1:
+                    c = min(a.cpu_sample, B)
+                    t1 = time.perf_counter()
+                    co.solve_batch("car", par, N, 50, 20, 1e-3, x0_np[:c], u0_np[:c], nthreads=cores, rule="lapack")
+                    dt = time.perf_counter() - t1
+                    t1 = time.perf_counter()
+                    co.solve_batch("car", par, N, 50, 20, 1e-3, x0_np[:c], u0_np[:c], nthreads=cores, rule="ldl")
+                    dt2 = time.perf_counter() - t1
+                    res["cpu_baseline"] = {"value": c / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+                                           "rule": "lapack",
+                                           "rule_note": "np.linalg.eigvals restated (DGEEV): the reference's own test, the "
+                                                        "partner of the `faithful` record; the headline `value` runs the "
+                                                        "kernels' default LDL' test, whose CPU partner is `ldl`",
+                                           "sample": f"first {c} trajectories of the same batch, C restatement of the "
+                                                     f"reference solver (oracle/), OpenMP over {cores} threads, {dt:.1f} s",
+                                           "ldl": {"value": c / dt2, "unit": "solves/s", "rule": "ldl",
+                                                   "sample": f"the same {c} trajectories with the kernels' LDL' rule, {dt2:.1f} s"}}
+            if world == 1 and a.faithful_batch != 0 and not a.lapack_eigvals:
+                fb = B if a.faithful_batch < 0 else min(a.faithful_batch, B)
+                res["faithful"] = faithful_record(dev, (0, [2.0, 2.0], N, 50, 20, 1e-3), x0[:, :fb].contiguous(),
+                                                  u_init[:, :, :fb].contiguous(), N, 1)
+                res["faithful"]["vs_headline"] = res["faithful"]["value"] / value
+        except Exception as e:      # noqa: BLE001
+            res["additions_failed"] = f"{type(e).__name__}: {e}"
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
