@@ -35,15 +35,18 @@ for k in sorted(disp):
     if not m:
         continue
     name = m.group(1)
+    lapack_long = name == "backward" and re.search(r"true, false>", d["name"]) is not None
+    if name == "backward" and re.search(r"true, (true|false)>", d["name"]):
+        name = "backward_lapack_long" if lapack_long else "backward_lapack"
     if name == "init":
         it = 0
-    if name == "backward":
+    if name in ("backward", "backward_lapack"):
         it += 1
     t = tot.setdefault(name, collections.Counter())
     for c, v in d.items():
         if c != "name":
             t[c] += v
-    if name == "backward" and it in show:
+    if name in ("backward", "backward_lapack_long") and it in show:
         per_it.append((it, d))
 print("all launches of the run, per kernel")
 for name, t in tot.items():
