@@ -244,32 +244,68 @@ struct Lane {
         do {                    // rows and columns k..l are scaled by powers of two until their norms are close
             noconv = false;
             for (int i = k; i <= l; ++i) {
-                double c = nrm2(l - k + 1, pA(k, i), ES);
-                double r = nrm2(l - k + 1, pA(i, k), W * ES);
                 double ca = 0.0, ra = 0.0;
                 for (int t = 1; t <= l; ++t) { const double v = __builtin_fabs(A(t, i)); if (v > ca) ca = v; }
                 for (int t = k; t <= n; ++t) { const double v = __builtin_fabs(A(i, t)); if (v > ra) ra = v; }
-                if (c == 0.0 || r == 0.0) continue;
-                double g = r / sclfac, f = 1.0;
-                const double s = c + r;
-                while (!(c >= g || mx(f, mx(c, ca)) >= sfmax2 || mn(r, mn(g, ra)) <= sfmin2)) {
-                    const double t = c + f + ca + r + g + ra;
-                    if (t != t) return false;
-                    f *= sclfac; c *= sclfac; ca *= sclfac;
-                    r /= sclfac; g /= sclfac; ra /= sclfac;
+                double f = 1.0;
+                bool act = false, settled = false;
+                {
+                    // What the norms c, r of column and row i decide is f, a power of two, and whether the pair is
+                    // scaled at all, both through comparisons of c and r times powers of two: functions of c / r, f a
+                    // monotone step function of it and the last test linear in it for a given f.  With all sizes far
+                    // from the over- and underflow guards, plainly summed norms settle both whenever the two ends of
+                    // their error interval (1e-12, a thousand times their rounding) agree; the extended-precision
+                    // norms are only taken where they do not.
+                    double c2 = 0.0, r2 = 0.0;
+                    for (int t = k; t <= l; ++t) {
+                        const double v = A(t, i), w2 = A(i, t);
+                        c2 = __builtin_fma(v, v, c2);
+                        r2 = __builtin_fma(w2, w2, r2);
+                    }
+                    const bool inrange = c2 > 1e-200 && c2 < 1e200 && r2 > 1e-200 && r2 < 1e200 && ca < 1e100 && ra < 1e100;
+                    if (inrange) {
+                        const double cp = __builtin_sqrt(c2), rp = __builtin_sqrt(r2);
+                        double fe[2];
+                        bool ae[2];
+                        for (int e = 0; e < 2; ++e) {
+                            double c = cp * (e ? 1.0 - 1e-12 : 1.0 + 1e-12), r = rp * (e ? 1.0 + 1e-12 : 1.0 - 1e-12);
+                            const double s0 = c + r;
+                            double ff = 1.0;
+                            while (c < r / sclfac) { ff *= sclfac; c *= sclfac; r /= sclfac; }
+                            while (c / sclfac >= r) { ff /= sclfac; c /= sclfac; r *= sclfac; }
+                            fe[e] = ff;
+                            ae[e] = !((c + r) >= factor * s0);
+                        }
+                        if (fe[0] == fe[1] && ae[0] == ae[1]) { f = fe[0]; act = ae[0]; settled = true; }
+                    }
                 }
-                g = c / sclfac;
-                while (!(g < r || mx(r, ra) >= sfmax2 || mn(mn(f, c), mn(g, ca)) <= sfmin2)) {
-                    f /= sclfac; c /= sclfac; g /= sclfac; ca /= sclfac;
-                    r *= sclfac; ra *= sclfac;
+                if (!settled) {
+                    double c = nrm2(l - k + 1, pA(k, i), ES);
+                    double r = nrm2(l - k + 1, pA(i, k), W * ES);
+                    if (c == 0.0 || r == 0.0) continue;
+                    double g = r / sclfac;
+                    const double s = c + r;
+                    while (!(c >= g || mx(f, mx(c, ca)) >= sfmax2 || mn(r, mn(g, ra)) <= sfmin2)) {
+                        const double t = c + f + ca + r + g + ra;
+                        if (t != t) return false;
+                        f *= sclfac; c *= sclfac; ca *= sclfac;
+                        r /= sclfac; g /= sclfac; ra /= sclfac;
+                    }
+                    g = c / sclfac;
+                    while (!(g < r || mx(r, ra) >= sfmax2 || mn(mn(f, c), mn(g, ca)) <= sfmin2)) {
+                        f /= sclfac; c /= sclfac; g /= sclfac; ca /= sclfac;
+                        r *= sclfac; ra *= sclfac;
+                    }
+                    act = !((c + r) >= factor * s);
                 }
-                if ((c + r) >= factor * s) continue;
+                if (!act) continue;
                 if (f < 1.0 && scale(i - 1) < 1.0) {
                     if (f * scale(i - 1) <= sfmin1) continue;
                 }
                 if (f > 1.0 && scale(i - 1) > 1.0) {
                     if (scale(i - 1) >= sfmax1 / f) continue;
                 }
+                double g;
                 g = 1.0 / f;
                 scale(i - 1) *= f;
                 noconv = true;
